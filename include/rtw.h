@@ -1,0 +1,230 @@
+/* rtw.h — C ABI of the MI355X wavefront path tracer (librtw_hip.so).
+ *
+ * This is the drop-in boundary for the reference's one device launch:
+ *
+ *   Director::renderFrame  ->  optixLaunch(pipeline, stream, d_params,
+ *                                          sizeof(SysParamter), &m_sbt, Nx, Ny, 1)
+ *                              (reference RestOfLife/Director.cpp:971-1008, launch at :982-984)
+ *
+ * and for the marshalling that feeds it:
+ *
+ *   Director::createSBT          (Director.cpp:628-885)  geometry records  -> rtw_prim[]
+ *   Director::initLaunchParams   (Director.cpp:483-553)  camera, materials, textures,
+ *                                                        lights, pdf tree  -> rtw_scene_header + arrays
+ *   SysParamter                  (shaders/sysparameter.h:32-60)            -> rtw_scene_header + rtw_params
+ *   HitGroupData / hitRectData / hitVolumeBoxdata (lib/raydata.cuh:79-115) -> rtw_prim
+ *   OptixInstance transform[12] / instanceId / sbtOffset
+ *                                (geometry/ioGeometryInstance.h:20-26)     -> rtw_xform + rtw_prim.material
+ *   MaterialParams / textureParam (sysparameter.h:5-16, raydata.cuh:127-138)-> rtw_material / rtw_texture
+ *   LightDefinition              (raydata.cuh:31-48)                       -> rtw_light
+ *   pdfCallfun                   (sysparameter.h:18-30)                    -> rtw_pdf
+ *
+ * Plain pointers and sizes only. No exceptions and no exit() cross this ABI:
+ * every call returns 0 on success or a negative rtw_status; the message is
+ * available from rtw_last_error().  Nothing is retained from caller pointers
+ * after a call returns.
+ */
+#ifndef RTW_H
+#define RTW_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTW_ABI_VERSION 1
+#define RTW_SCENE_MAGIC 0x57545221u /* "!RTW" */
+
+typedef enum rtw_status {
+    RTW_OK = 0,
+    RTW_ERR_INVALID_ARG = -1,
+    RTW_ERR_BAD_SCENE = -2,
+    RTW_ERR_NO_SCENE = -3,
+    RTW_ERR_DEVICE = -4,
+    RTW_ERR_OOM = -5,
+    RTW_ERR_UNSUPPORTED = -6
+} rtw_status;
+
+/* Primitive kinds. One per reference intersection program
+ * (Director.h ProgramIdentifier PROGRAM_ID_IS_*; geometry/sphere.cu, movingSphere.cu,
+ * shaders/aarect{x,y,z}.cu, geometry/volumeBox.cu, volumeSphere.cu). */
+typedef enum rtw_prim_type {
+    RTW_PRIM_SPHERE = 0,        /* p[0..2] centre, p[3] radius                                   */
+    RTW_PRIM_MOVING_SPHERE = 1, /* p[0..2] centre0, p[3] radius, p[4..6] centre1, p[7] t0, p[8] t1;
+                                   carries the reference's matrix-motion transform translate(C0)->translate(C1)
+                                   (geometry/ioMovingSphere.h:161-203) on top of its xform             */
+    RTW_PRIM_RECT_X = 2,        /* p[0] a0 p[1] a1 p[2] b0 p[3] b1 p[4] k ; a=y b=z (aarectx.cu)  */
+    RTW_PRIM_RECT_Y = 3,        /*                                          a=x b=z (aarecty.cu)  */
+    RTW_PRIM_RECT_Z = 4,        /*                                          a=x b=y (aarectz.cu)  */
+    RTW_PRIM_VOLUME_BOX = 5,    /* p[0..2] boxMin, p[3..5] boxMax, p[6] density                   */
+    RTW_PRIM_VOLUME_SPHERE = 6  /* p[0..2] centre, p[3] radius, p[4] density                      */
+} rtw_prim_type;
+
+/* Same numbering as MaterialType, lib/raydata.cuh:22-29. */
+typedef enum rtw_material_type {
+    RTW_MAT_LAMBERTIAN = 0,
+    RTW_MAT_DIFFUSE_LIGHT = 1,
+    RTW_MAT_METAL = 2,
+    RTW_MAT_DIELECTRIC = 3,
+    RTW_MAT_ISOTROPIC = 4,
+    RTW_MAT_NORMAL = 5
+} rtw_material_type;
+
+/* Same numbering as TexCallFunction, shaders/FunctionIdx.h:8-15. */
+typedef enum rtw_texture_type {
+    RTW_TEX_CHECKER = 0,
+    RTW_TEX_CONSTANT = 1,
+    RTW_TEX_IMAGE = 2,
+    RTW_TEX_NOISE = 3,
+    RTW_TEX_NULL = 4
+} rtw_texture_type;
+
+/* Same numbering as PDFCallFunction generate ids, shaders/FunctionIdx.h:27-33. */
+typedef enum rtw_pdf_gen {
+    RTW_PDF_COSINE = 0,
+    RTW_PDF_MIXTURE_BIAS = 1,
+    RTW_PDF_MIXTURE = 2,
+    RTW_PDF_RECT_X = 3,
+    RTW_PDF_RECT_Y = 4,
+    RTW_PDF_RECT_Z = 5
+} rtw_pdf_gen;
+
+typedef enum rtw_rng_kind {
+    RTW_RNG_PHILOX = 0,  /* Philox4x32-10, key=(seed,0), counter=(pixel, sample, block, stream)        */
+    RTW_RNG_TEA_LCG = 1  /* the reference's own: tea<64>(pixel, sample) + 24-bit LCG rnd() + xorshift
+                            randf() (lib/random.cuh:7-38, raygen/raygen.cu:129)                       */
+} rtw_rng_kind;
+
+typedef struct rtw_prim {
+    int32_t type;     /* rtw_prim_type                                                             */
+    int32_t material; /* index into materials[] (== OptixInstance.instanceId, closehit.cu:50,63)  */
+    int32_t xform;    /* index into xforms[]; 0 is the identity                                   */
+    int32_t flip;     /* rects: hitRectData.flip                                                   */
+    float p[12];
+} rtw_prim; /* 64 B */
+
+/* Object->world 3x4 row-major (OptixInstance.transform) and its inverse (world->object). */
+typedef struct rtw_xform {
+    float m[12];
+    float inv[12];
+} rtw_xform; /* 96 B */
+
+typedef struct rtw_material {
+    int32_t type;       /* rtw_material_type                        */
+    int32_t texture;    /* index into textures[] or -1              */
+    float fuzz_or_eta;  /* MaterialParams union{fuzz,eta}           */
+    int32_t bsdf_eval;  /* MaterialParams.lightreflectIdx - CALLABLE_ID_LIGHT_SAMPLE_PDF: 0 diffuse, 1 dielectric, 2 metal, -1 none */
+} rtw_material; /* 16 B */
+
+typedef struct rtw_texture {
+    int32_t type; /* rtw_texture_type */
+    float color[3];
+    int32_t odd, even;
+    float scale;
+    int32_t reserved;
+} rtw_texture; /* 32 B */
+
+typedef struct rtw_light {
+    float position[3];
+    float vec_u[3];
+    float vec_v[3];
+    float normal[3];
+    float area;
+    float emission[3];
+} rtw_light; /* 64 B */
+
+typedef struct rtw_pdf {
+    int32_t gen;     /* top-level generate id (rtw_pdf_gen), e.g. RTW_PDF_MIXTURE */
+    int32_t p0_gen;  /* mixture child 0 (cosine) or -1                          */
+    int32_t p1_gen;  /* mixture child 1 (rect x/y/z) or -1                      */
+    int32_t flip;
+    float rect[5];   /* p1's hitRectData a0,a1,b0,b1,k                          */
+    float bias;
+    float reserved[2];
+} rtw_pdf; /* 48 B */
+
+typedef struct rtw_camera {
+    float origin[3];
+    float u[3], v[3], w[3];
+    float lower_left[3];
+    float horizontal[3];
+    float vertical[3];
+    float lens_radius; /* SysParamter.cameraLensRadius (never set by the reference: 0) */
+    float time0, time1;
+} rtw_camera; /* 96 B */
+
+/* The scene blob is this header followed by the arrays at the given byte offsets
+ * (all offsets relative to the start of the header, 16-byte aligned). */
+typedef struct rtw_scene_header {
+    uint32_t magic;   /* RTW_SCENE_MAGIC */
+    uint32_t version; /* RTW_ABI_VERSION */
+    uint32_t total_bytes;
+    uint32_t n_prims, n_xforms, n_materials, n_textures, n_lights;
+    uint32_t off_prims, off_xforms, off_materials, off_textures, off_lights;
+    int32_t sky_light; /* SysParamter.skyLight */
+    uint32_t reserved[2];
+    rtw_camera camera;
+    rtw_pdf pdf;
+} rtw_scene_header;
+
+typedef struct rtw_params {
+    int32_t width, height;     /* full image (launch dimensions of the reference's optixLaunch) */
+    int32_t spp;               /* samples per pixel rendered by this call                       */
+    int32_t max_depth;         /* SysParamter.maxRayDepth                                       */
+    uint32_t seed;
+    int32_t row0, row1;        /* rows [row0,row1) of the full image are rendered (row-tile shard) */
+    int32_t rng_kind;          /* rtw_rng_kind                                                  */
+    int32_t sample_offset;     /* first sample index (progressive / resumed renders)            */
+    int32_t samples_per_pass;  /* paths kept in flight = rows*width*samples_per_pass; 0 = auto  */
+    int32_t reserved[2];
+} rtw_params;
+
+typedef struct rtw_stats {
+    uint64_t samples;           /* camera paths started                                              */
+    uint64_t segments;          /* radiance ray segments traced (one optixTraverse of raygen.cu:41) */
+    uint64_t shadow_rays;       /* occlusion probes traced (closehit.cu:95-101)                     */
+    uint64_t algorithmic_bytes; /* 128*segments + 32*samples                 */
+    uint64_t bounce_launches;   /* launches of the dominant kernel                                  */
+    uint64_t reserved;
+    double seconds;             /* device time of the whole render call (events on the stream)     */
+    double bounce_seconds;      /* device time inside the bounce-kernel loops only                 */
+} rtw_stats;
+
+typedef struct rtw_ctx rtw_ctx;
+
+int rtw_abi_version(void);
+
+/* Replaces Director::initContext (Director.cpp:106-122). One context per GPU. */
+int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids);
+
+/* Replaces createSBT + initLaunchParams + the per-primitive optixAccelBuild calls
+ * (Director.cpp:628-885, 483-553; geometry/io*.h init()). Copies the blob, builds the BVH. */
+int rtw_upload_scene(rtw_ctx* ctx, const void* scene_blob, size_t bytes);
+
+/* Replaces optixLaunch + the D2H copy (Director.cpp:982-984, 999-1000).
+ * rgba_out: host, (row1-row0)*width float4, LINEAR mean radiance, alpha 1; row r of the tile is image row row0+r. */
+int rtw_render(rtw_ctx* ctx, const rtw_params* params, float* rgba_out, rtw_stats* stats);
+
+/* Same render, result left in device memory (d_rgba: device pointer, same layout), launched on
+ * hip_stream (a hipStream_t passed as void*, NULL = the context's own stream). Returns when done. */
+int rtw_render_device(rtw_ctx* ctx, const rtw_params* params, void* d_rgba, void* hip_stream,
+                      rtw_stats* stats);
+
+/* Replaces Director::destroy (Director.cpp:66-104). */
+int rtw_destroy(rtw_ctx* ctx);
+
+const char* rtw_last_error(rtw_ctx* ctx);
+
+/* Test hooks (no reference counterpart): one closest-hit query per ray on the GPU accel structure,
+ * used by the parity tests to compare BVH traversal with the oracle's brute force.
+ * rays: n*8 floats (ox,oy,oz,dx,dy,dz,tmin,tmax); ray_time: n floats or NULL;
+ * out_t: n floats (tmax if miss); out_prim: n int32 (-1 if miss). All host pointers. */
+int rtw_debug_intersect(rtw_ctx* ctx, const float* rays, const float* ray_time, const float* gather_time,
+                        int n, float* out_t, int32_t* out_prim);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTW_H */

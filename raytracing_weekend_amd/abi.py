@@ -1,0 +1,232 @@
+"""ctypes mirror of include/rtw.h and loaders for the in-tree shared libraries.
+
+Plumbing only: scene blobs come from the C++ host description (librtw_host.so), rendering is
+done by the HIP library (librtw_hip.so) through its C ABI. There is no Python or CPU fallback:
+`load_hip()` raises if the HIP library has not been built.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+REPO_DIR = os.path.dirname(PKG_DIR)
+HOST_LIB = os.path.join(PKG_DIR, "host", "librtw_host.so")
+HIP_LIB = os.path.join(PKG_DIR, "csrc", "librtw_hip.so")
+
+RTW_ABI_VERSION = 1
+RTW_SCENE_MAGIC = 0x57545221
+RTW_RNG_PHILOX = 0
+RTW_RNG_TEA_LCG = 1
+
+# rtw_prim_type
+PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_RECT_X, PRIM_RECT_Y, PRIM_RECT_Z, PRIM_VOLUME_BOX, PRIM_VOLUME_SPHERE = range(7)
+# rtw_material_type
+MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_METAL, MAT_DIELECTRIC, MAT_ISOTROPIC, MAT_NORMAL = range(6)
+
+
+class Prim(C.Structure):
+    _fields_ = [("type", C.c_int32), ("material", C.c_int32), ("xform", C.c_int32), ("flip", C.c_int32),
+                ("p", C.c_float * 12)]
+
+
+class Xform(C.Structure):
+    _fields_ = [("m", C.c_float * 12), ("inv", C.c_float * 12)]
+
+
+class Material(C.Structure):
+    _fields_ = [("type", C.c_int32), ("texture", C.c_int32), ("fuzz_or_eta", C.c_float), ("bsdf_eval", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("odd", C.c_int32), ("even", C.c_int32),
+                ("scale", C.c_float), ("reserved", C.c_int32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("position", C.c_float * 3), ("vec_u", C.c_float * 3), ("vec_v", C.c_float * 3),
+                ("normal", C.c_float * 3), ("area", C.c_float), ("emission", C.c_float * 3)]
+
+
+class Pdf(C.Structure):
+    _fields_ = [("gen", C.c_int32), ("p0_gen", C.c_int32), ("p1_gen", C.c_int32), ("flip", C.c_int32),
+                ("rect", C.c_float * 5), ("bias", C.c_float), ("reserved", C.c_float * 2)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("u", C.c_float * 3), ("v", C.c_float * 3), ("w", C.c_float * 3),
+                ("lower_left", C.c_float * 3), ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("lens_radius", C.c_float), ("time0", C.c_float), ("time1", C.c_float)]
+
+
+class SceneHeader(C.Structure):
+    _fields_ = [("magic", C.c_uint32), ("version", C.c_uint32), ("total_bytes", C.c_uint32),
+                ("n_prims", C.c_uint32), ("n_xforms", C.c_uint32), ("n_materials", C.c_uint32),
+                ("n_textures", C.c_uint32), ("n_lights", C.c_uint32),
+                ("off_prims", C.c_uint32), ("off_xforms", C.c_uint32), ("off_materials", C.c_uint32),
+                ("off_textures", C.c_uint32), ("off_lights", C.c_uint32),
+                ("sky_light", C.c_int32), ("reserved", C.c_uint32 * 2),
+                ("camera", Camera), ("pdf", Pdf)]
+
+
+class Params(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
+                ("seed", C.c_uint32), ("row0", C.c_int32), ("row1", C.c_int32), ("rng_kind", C.c_int32),
+                ("sample_offset", C.c_int32), ("samples_per_pass", C.c_int32), ("reserved", C.c_int32 * 2)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
+                ("algorithmic_bytes", C.c_uint64), ("bounce_launches", C.c_uint64), ("reserved", C.c_uint64),
+                ("seconds", C.c_double), ("bounce_seconds", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+HIP_SYMBOLS = ["rtw_abi_version", "rtw_create", "rtw_upload_scene", "rtw_render", "rtw_render_device",
+               "rtw_destroy", "rtw_last_error", "rtw_debug_intersect"]
+
+_host = None
+_hip = None
+
+
+def load_host():
+    global _host
+    if _host is None:
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError(f"{HOST_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(HOST_LIB)
+        lib.rtw_host_build_scene.restype = C.c_int
+        lib.rtw_host_build_scene.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        _host = lib
+    return _host
+
+
+def load_hip():
+    """Load librtw_hip.so. Fails loudly when it is absent: there is no fallback path."""
+    global _hip
+    if _hip is None:
+        if not os.path.exists(HIP_LIB):
+            raise RuntimeError(f"{HIP_LIB} is missing: the HIP extension must be built "
+                               "(`python -c 'import __graft_entry__ as g; g.build()'`); no CPU fallback exists")
+        lib = C.CDLL(HIP_LIB)
+        lib.rtw_abi_version.restype = C.c_int
+        lib.rtw_create.restype = C.c_int
+        lib.rtw_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_int)]
+        lib.rtw_upload_scene.restype = C.c_int
+        lib.rtw_upload_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        lib.rtw_render.restype = C.c_int
+        lib.rtw_render.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.POINTER(Stats)]
+        lib.rtw_render_device.restype = C.c_int
+        lib.rtw_render_device.argtypes = [C.c_void_p, C.POINTER(Params), C.c_void_p, C.c_void_p, C.POINTER(Stats)]
+        lib.rtw_destroy.restype = C.c_int
+        lib.rtw_destroy.argtypes = [C.c_void_p]
+        lib.rtw_last_error.restype = C.c_char_p
+        lib.rtw_last_error.argtypes = [C.c_void_p]
+        lib.rtw_debug_intersect.restype = C.c_int
+        lib.rtw_debug_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        if lib.rtw_abi_version() != RTW_ABI_VERSION:
+            raise RuntimeError("librtw_hip.so ABI version mismatch")
+        _hip = lib
+    return _hip
+
+
+def build_scene(scene, nx, ny):
+    """Scene blob (bytes) of reference scene 0/1/3 for an nx x ny image, from the C++ host description."""
+    lib = load_host()
+    need = C.c_size_t(0)
+    rc = lib.rtw_host_build_scene(scene, nx, ny, None, 0, C.byref(need))
+    if rc == -1:
+        raise ValueError(f"unknown scene {scene}")
+    buf = C.create_string_buffer(need.value)
+    rc = lib.rtw_host_build_scene(scene, nx, ny, buf, need.value, C.byref(need))
+    if rc != 0:
+        raise RuntimeError(f"rtw_host_build_scene failed: {rc}")
+    return buf.raw
+
+
+def parse_scene(blob):
+    """Decode a scene blob into ctypes views (header, prims, xforms, materials, textures, lights)."""
+    h = SceneHeader.from_buffer_copy(blob[:C.sizeof(SceneHeader)])
+
+    def arr(t, off, n):
+        return (t * n).from_buffer_copy(blob[off:off + n * C.sizeof(t)])
+    return {
+        "header": h,
+        "prims": arr(Prim, h.off_prims, h.n_prims),
+        "xforms": arr(Xform, h.off_xforms, h.n_xforms),
+        "materials": arr(Material, h.off_materials, h.n_materials),
+        "textures": arr(Texture, h.off_textures, h.n_textures),
+        "lights": arr(Light, h.off_lights, h.n_lights),
+    }
+
+
+def make_params(width, height, spp, max_depth, seed=0x6314759, row0=0, row1=None, rng_kind=RTW_RNG_PHILOX,
+                sample_offset=0, samples_per_pass=0):
+    p = Params()
+    p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
+    p.seed = seed
+    p.row0 = row0
+    p.row1 = height if row1 is None else row1
+    p.rng_kind = rng_kind
+    p.sample_offset = sample_offset
+    p.samples_per_pass = samples_per_pass
+    return p
+
+
+class Renderer:
+    """Thin owner of one rtw_ctx (one GPU)."""
+
+    def __init__(self, device=0):
+        self.lib = load_hip()
+        self.ctx = C.c_void_p()
+        dev = (C.c_int * 1)(device)
+        rc = self.lib.rtw_create(C.byref(self.ctx), 1, dev)
+        if rc != 0:
+            raise RuntimeError(f"rtw_create failed: {rc}")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.rtw_last_error(self.ctx)
+            raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    def upload_scene(self, blob):
+        self._check(self.lib.rtw_upload_scene(self.ctx, blob, len(blob)), "rtw_upload_scene")
+
+    def render(self, params):
+        rows = params.row1 - params.row0
+        out = np.empty((rows, params.width, 4), dtype=np.float32)
+        st = Stats()
+        self._check(self.lib.rtw_render(self.ctx, C.byref(params), out.ctypes.data, C.byref(st)), "rtw_render")
+        return out, st
+
+    def render_device(self, params, device_ptr, stream_ptr=0):
+        st = Stats()
+        self._check(self.lib.rtw_render_device(self.ctx, C.byref(params), C.c_void_p(device_ptr),
+                                               C.c_void_p(stream_ptr), C.byref(st)), "rtw_render_device")
+        return st
+
+    def debug_intersect(self, rays, ray_time=None, gather_time=None):
+        rays = np.ascontiguousarray(rays, dtype=np.float32)
+        n = rays.shape[0]
+        rt = None if ray_time is None else np.ascontiguousarray(ray_time, dtype=np.float32)
+        gt = None if gather_time is None else np.ascontiguousarray(gather_time, dtype=np.float32)
+        t = np.empty(n, dtype=np.float32)
+        prim = np.empty(n, dtype=np.int32)
+        self._check(self.lib.rtw_debug_intersect(self.ctx, rays.ctypes.data,
+                                                 None if rt is None else rt.ctypes.data,
+                                                 None if gt is None else gt.ctypes.data,
+                                                 n, t.ctypes.data, prim.ctypes.data), "rtw_debug_intersect")
+        return t, prim
+
+    def close(self):
+        if self.ctx:
+            self.lib.rtw_destroy(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,272 @@
+// ioScene.h — the hard-coded scenes, as in the reference's scene/ioScene.h:
+//   0 CornellBox          (ioScene.h:491-627)   metric scene
+//   1 MovingSpheres       (ioScene.h:180-309)   "In One Weekend" final scene, 70% moving spheres
+//   3 VolumesCornellBox   (ioScene.h:630-788)   Cornell box with two participating media
+// Scenes 2 and 4 need checker / noise / image textures (next) and are rejected.
+// Primitive i, material i and instance i line up, as the reference relies on
+// (geometryList.size()==materialList.size(), ioScene.h:262,426,581).
+#pragma once
+#include <cstdint>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "ioCamera.h"
+#include "ioGeometry.h"
+
+namespace rtwhost {
+
+// lib/random.cuh:22-38 — the scene layouts are drawn with the reference's xorshift32/randf.
+inline uint32_t xorshift32(uint32_t& s) {
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    return s;
+}
+inline float randf(uint32_t& s) {
+    float r = static_cast<float>(xorshift32(s)) / 4294967296.0f;
+    return r != 1.0f ? r : static_cast<float>(0x3F7FFFFF);
+}
+
+// sysparameter.h:18-30 / ioScene.h:35-46, flattened: generate ids of the pdf tree
+struct pdfCallfun_host {
+    int pdfGenIdx = RTW_PDF_COSINE;
+    int p0GenIdx = -1;
+    int p1GenIdx = -1;
+    float pdfrect[5] = {0, 0, 0, 0, 0};
+    int flip = 0;
+    float bias = 0.f;
+};
+
+class ioScene {
+public:
+    // returns non-zero for an unknown scene, like ioScene::init (ioScene.h:52-101)
+    int init(int Nx, int Ny, int Ns, int maxRayDepth, int Nscene) {
+        m_Nx = Nx; m_Ny = Ny; m_numSamples = Ns; m_maxRayDepth = maxRayDepth;
+        destroy();
+        if (getScenePdf(Nscene)) return 1;
+        switch (Nscene) {
+        case 0: CornellBox(); break;
+        case 1: MovingSpheres(); break;
+        case 3: VolumesCornellBox(); break;
+        default:
+            std::cerr << "ERROR: Scene " << Nscene << " unknown." << std::endl;
+            return 1;
+        }
+        return 0;
+    }
+
+    void destroy() {
+        geometryList.clear(); materialList.clear(); geoInstList.clear(); m_lightDefinitions.clear();
+        ownedTextures.clear(); ownedMaterials.clear(); camera.reset();
+    }
+
+    std::string getDescription() const { return sceneDescription; }
+
+    std::vector<std::unique_ptr<ioGeometry>> geometryList;
+    std::vector<const ioMaterial*> materialList;
+    std::vector<ioGeometryInstance> geoInstList;
+    std::vector<rtw_light> m_lightDefinitions;
+    pdfCallfun_host MCpdf;
+    std::unique_ptr<ioPerspectiveCamera> camera;
+
+private:
+    // ioScene.h:103-148
+    int getScenePdf(int Nscene) {
+        MCpdf = pdfCallfun_host();
+        switch (Nscene) {
+        case 0:
+            MCpdf.pdfGenIdx = RTW_PDF_MIXTURE; MCpdf.p0GenIdx = RTW_PDF_COSINE; MCpdf.p1GenIdx = RTW_PDF_RECT_Y;
+            setRect(213.f, 343.f, 227.f, 332.f, 554.9f);
+            return 0;
+        case 1:
+            MCpdf.pdfGenIdx = RTW_PDF_COSINE;
+            return 0;
+        case 3:
+            MCpdf.pdfGenIdx = RTW_PDF_MIXTURE; MCpdf.p0GenIdx = RTW_PDF_COSINE; MCpdf.p1GenIdx = RTW_PDF_RECT_Y;
+            setRect(213.f, 343.f, 227.f, 332.f, 554.f);
+            return 0;
+        default:
+            std::cerr << "ERROR: Scene " << Nscene << " unknown." << std::endl;
+            return 1;
+        }
+    }
+    void setRect(float a0, float a1, float b0, float b1, float k) {
+        MCpdf.pdfrect[0] = a0; MCpdf.pdfrect[1] = a1; MCpdf.pdfrect[2] = b0; MCpdf.pdfrect[3] = b1; MCpdf.pdfrect[4] = k;
+    }
+
+    const ioTexture* tex(ioTexture* t) { ownedTextures.emplace_back(t); return t; }
+    const ioMaterial* mat(ioMaterial* m) { ownedMaterials.emplace_back(m); return m; }
+
+    void identityInstances() {
+        geoInstList.resize(geometryList.size());
+        for (size_t i = 0; i < geoInstList.size(); i++) geoInstList[i].init(static_cast<unsigned>(i), static_cast<unsigned>(i));
+    }
+
+    // ---------------------------------------------------------------- scene 0
+    void CornellBox() {
+        sceneDescription = "Cornell box";
+        const ioMaterial* wallRed = mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(0.65f, 0.05f, 0.05f)))));
+        const ioMaterial* wallGreen = mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(0.12f, 0.45f, 0.15f)))));
+        const ioMaterial* wallWhite = mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(0.73f, 0.73f, 0.73f)))));
+        const ioMaterial* aluminum = mat(new ioMetalMaterial(tex(new ioConstantTexture(make_float3(0.91f, 0.92f, 0.92f))), 0.018f));
+        const ioTexture* light15 = tex(new ioConstantTexture(make_float3(15.f, 15.f, 15.f)));
+
+        geometryList.emplace_back(new ioSphere(190.f, 90.f, 190.f, 90.f));  // medium glass sphere
+        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 555.f, true, X_AXIS));   // left wall
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 0.f, false, X_AXIS));    // right wall
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 555.f, true, Y_AXIS));   // roof
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 0.f, false, Y_AXIS));    // floor
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 555.f, true, Z_AXIS));   // back wall
+        geometryList.emplace_back(new ioAARect(213.f, 343.f, 227.f, 332.f, 554.9f, true, Y_AXIS));  // light
+        materialList.push_back(wallGreen);
+        materialList.push_back(wallRed);
+        materialList.push_back(wallWhite);
+        materialList.push_back(wallWhite);
+        materialList.push_back(wallWhite);
+        materialList.push_back(mat(new ioDiffuseLightMaterial(light15)));
+
+        // aluminium box: six rects under T(265,0,295) * R_y(15 deg)   (ioScene.h:537-548)
+        Float3 b1size = make_float3(165.f, 330.f, 165.f);
+        Float3 b1tr = make_float3(265.f, 0.f, 295.f);
+        ioGeometryGroup::createBox(make_float3(0.f), b1size, geometryList);
+        for (int i = 0; i < 6; i++) materialList.push_back(aluminum);
+        Mat4 transf = ioTransform::translate(b1tr);
+        transf *= ioTransform::rotateY(15.f);
+
+        identityInstances();
+        for (size_t i = 7; i < 13; i++) geoInstList[i].setTransform(transf);
+
+        // ioScene.h:605-612
+        rtw_light light{};
+        Float3 vecU = make_float3(343.f - 213.f, 0.f, 0.f), vecV = make_float3(0.f, 0.f, 332.f - 227.f);
+        Float3 c = cross(vecU, vecV), n = normalize(c);
+        light.emission[0] = light.emission[1] = light.emission[2] = 15.f;
+        light.vec_u[0] = vecU.x; light.vec_u[1] = vecU.y; light.vec_u[2] = vecU.z;
+        light.vec_v[0] = vecV.x; light.vec_v[1] = vecV.y; light.vec_v[2] = vecV.z;
+        light.position[0] = 213.f; light.position[1] = 554.f; light.position[2] = 227.f;
+        light.area = length(c);
+        light.normal[0] = n.x; light.normal[1] = n.y; light.normal[2] = n.z;
+        m_lightDefinitions.push_back(light);
+
+        camera.reset(new ioPerspectiveCamera(278.f, 278.f, -800.f, 278.f, 278.f, 0.f, 0.0f, 1.0f, 0.0f, 40.0f,
+                                             float(m_Nx) / float(m_Ny), /*aperture*/ 1.f, /*focus_distance*/ 10.f, 0.f, 1.f));
+    }
+
+    // ---------------------------------------------------------------- scene 1
+    void MovingSpheres() {
+        sceneDescription = "InOneWeekend final scene with moving spheres";
+        const ioTexture* fiftyPercentGrey = tex(new ioConstantTexture(make_float3(0.5f, 0.5f, 0.5f)));
+        const ioTexture* fiftyPercentReddishGrey = tex(new ioConstantTexture(make_float3(0.7f, 0.6f, 0.5f)));
+        const ioTexture* reddish = tex(new ioConstantTexture(make_float3(0.4f, 0.2f, 0.1f)));
+
+        geometryList.emplace_back(new ioSphere(0.0f, -1000.0f, 0.0f, 1000.0f));  // ground
+        materialList.push_back(mat(new ioLambertianMaterial(fiftyPercentGrey)));
+        geometryList.emplace_back(new ioSphere(0.0f, 1.0f, 0.0f, 1.0f));
+        geometryList.emplace_back(new ioSphere(-4.0f, 1.0f, 0.0f, 1.0f));
+        geometryList.emplace_back(new ioSphere(4.0f, 1.0f, 0.0f, 1.0f));
+        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+        materialList.push_back(mat(new ioLambertianMaterial(reddish)));
+        materialList.push_back(mat(new ioMetalMaterial(fiftyPercentReddishGrey, 0.1f)));
+
+        // Small spheres, ioScene.h:201-253. Where the reference draws several randf() inside one
+        // argument list the order is unspecified C++; the reference only builds with
+        // MSVC, which evaluates arguments right to left, so that order is used here.
+        uint32_t seed = 0x314759;
+        for (int a = -11; a < 11; a++) {
+            for (int b = -11; b < 11; b++) {
+                float chooseMat = randf(seed);
+                float x = a + 0.8f * randf(seed);
+                float y = 0.2f;
+                float z = b + 0.9f * randf(seed);
+                float z_squared = z * z;
+                float dist = sqrtf((x - 4.0f) * (x - 4.0f) + z_squared);
+                if ((dist > 0.9f) || ((z_squared > 0.7f) && ((x * x - 16.0f) > -2.f))) {
+                    if (chooseMat < 0.70f) {
+                        geometryList.emplace_back(new ioMovingSphere(x, y, z, x, y + 0.18f, z, 0.2f, 0.f, 1.f));
+                        float cb = randf(seed), cg = randf(seed), cr = randf(seed);
+                        materialList.push_back(mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))))));
+                    } else if (chooseMat < 0.85f) {
+                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
+                        float fuzz = 0.5f * randf(seed);
+                        float cb = 0.5f * (1.0f - randf(seed));
+                        float cg = 0.5f * (1.0f - randf(seed));
+                        float cr = 0.5f * (1.0f - randf(seed));
+                        materialList.push_back(mat(new ioMetalMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))), fuzz)));
+                    } else if (chooseMat < 0.93f) {
+                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
+                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+                    } else {
+                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
+                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+                        geometryList.emplace_back(new ioSphere(x, y, z, (0.2f - 0.007f)));
+                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+                    }
+                }
+            }
+        }
+        identityInstances();
+        camera.reset(new ioPerspectiveCamera(13.0f, 2.0f, 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 20.0f,
+                                             float(m_Nx) / float(m_Ny), /*aperture*/ 0.1f, /*focus_distance*/ 10.f, 0.f, 1.f));
+        // no light definition: the sky lights the scene (Director.cpp:523-524)
+    }
+
+    // ---------------------------------------------------------------- scene 3
+    void VolumesCornellBox() {
+        sceneDescription = "Cornell box with volumes (participating media)";
+        const ioMaterial* wallRed = mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(0.65f, 0.05f, 0.05f)))));
+        const ioMaterial* wallGreen = mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(0.12f, 0.45f, 0.15f)))));
+        const ioMaterial* wallWhite = mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(0.73f, 0.73f, 0.73f)))));
+        const ioTexture* light15 = tex(new ioConstantTexture(make_float3(15.f, 15.f, 15.f)));
+        const ioMaterial* blackFog = mat(new ioIsotropicMaterial(tex(new ioConstantTexture(make_float3(0.f)))));
+        const ioMaterial* whiteFog = mat(new ioIsotropicMaterial(tex(new ioConstantTexture(make_float3(1.f)))));
+
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 555.f, true, X_AXIS));
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 0.f, false, X_AXIS));
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 555.f, true, Y_AXIS));
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 0.f, false, Y_AXIS));
+        geometryList.emplace_back(new ioAARect(0.f, 555.f, 0.f, 555.f, 555.f, true, Z_AXIS));
+        geometryList.emplace_back(new ioAARect(213.f, 343.f, 227.f, 332.f, 554.f, true, Y_AXIS));  // light
+        materialList.push_back(wallGreen);
+        materialList.push_back(wallRed);
+        materialList.push_back(wallWhite);
+        materialList.push_back(wallWhite);
+        materialList.push_back(wallWhite);
+        materialList.push_back(mat(new ioDiffuseLightMaterial(light15)));
+
+        // black fog box, T(b1tr) * R_z(-12.5 deg) * R_y(15 deg)   (ioScene.h:694-715)
+        const float z1Theta = -12.5f * (kPiF / 180.f);
+        Float3 b1size = make_float3(165.f, 330.f, 165.f);
+        Float3 b1tr = make_float3(265.f, fabsf(sinf(z1Theta)) * b1size.x + 0.f, 255.f);
+        materialList.push_back(blackFog);
+        geometryList.emplace_back(new ioVolumeBox(make_float3(0.f), b1size, 0.006f));
+        Mat4 trans = ioTransform::translate(b1tr);
+        trans *= ioTransform::rotateZ(z1Theta * (180.f / kPiF));
+        trans *= ioTransform::rotateY(15.f);
+
+        // white fog sphere, T(130,0,65)   (ioScene.h:741-749)
+        Float3 b2origin = make_float3(165.f / 2.f, 75.f, 165.f / 2.f);
+        Float3 b2tr = make_float3(130.f, 0.f, 65.f);
+        materialList.push_back(whiteFog);
+        geometryList.emplace_back(new ioVolumeSphere(b2origin.x, b2origin.y, b2origin.z, 75.f, 0.005f));
+        Mat4 trans2 = ioTransform::translate(b2tr);
+
+        identityInstances();
+        geoInstList[6].setTransform(trans);
+        geoInstList[7].setTransform(trans2);
+
+        // no m_lightDefinitions.push_back: numLights 0, sky light on
+        camera.reset(new ioPerspectiveCamera(278.f, 278.f, -800.f, 278.f, 278.f, 0.f, 0.0f, 1.0f, 0.0f, 40.0f,
+                                             float(m_Nx) / float(m_Ny), /*aperture*/ 0.1f, /*focus_distance*/ 10.f));
+    }
+
+    int m_Nx = 0, m_Ny = 0, m_numSamples = 0, m_maxRayDepth = 0;
+    std::string sceneDescription;
+    std::vector<std::unique_ptr<ioTexture>> ownedTextures;
+    std::vector<std::unique_ptr<ioMaterial>> ownedMaterials;
+};
+
+}  // namespace rtwhost
