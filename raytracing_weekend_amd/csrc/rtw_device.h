@@ -1,0 +1,553 @@
+// rtw_device.h — device-side math, RNG, intersection and shading for the gfx950 wavefront kernels.
+//
+// Arithmetic contract (DESIGN.md "arithmetic spec"): fp32, compiled -ffp-contract=off, fused
+// multiply-add only where __builtin_fmaf is written, IEEE-correct division and sqrt (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt), own polynomial sincos / log. The same operations in
+// the same order are stated independently in oracle/rtw_oracle.c, which is what the parity tests
+// check this file against.
+//
+// Each function cites the reference device code it replaces (paths under RestOfLife/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtw.h"
+
+#define RTW_DEV __device__ __forceinline__
+
+namespace rtwdev {
+
+struct v3 { float x, y, z; };
+
+RTW_DEV v3 V(float x, float y, float z) { v3 r; r.x = x; r.y = y; r.z = z; return r; }
+RTW_DEV v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+RTW_DEV v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+RTW_DEV v3 vmul(v3 a, v3 b) { return V(a.x * b.x, a.y * b.y, a.z * b.z); }
+RTW_DEV v3 vscale(v3 a, float s) { return V(a.x * s, a.y * s, a.z * s); }
+RTW_DEV v3 vneg(v3 a) { return V(-a.x, -a.y, -a.z); }
+RTW_DEV float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+RTW_DEV v3 vfma(v3 a, float s, v3 b) { return V(fma_(a.x, s, b.x), fma_(a.y, s, b.y), fma_(a.z, s, b.z)); }
+RTW_DEV float dot3(v3 a, v3 b) { return fma_(a.z, b.z, fma_(a.y, b.y, a.x * b.x)); }
+RTW_DEV v3 cross3(v3 a, v3 b) {
+    return V(fma_(a.y, b.z, -(a.z * b.y)), fma_(a.z, b.x, -(a.x * b.z)), fma_(a.x, b.y, -(a.y * b.x)));
+}
+RTW_DEV v3 normalize3(v3 a) { float inv = 1.0f / __builtin_sqrtf(dot3(a, a)); return vscale(a, inv); }
+RTW_DEV float length3(v3 a) { return __builtin_sqrtf(dot3(a, a)); }
+RTW_DEV v3 ld3(const float* p) { return V(p[0], p[1], p[2]); }
+
+RTW_DEV v3 xf_point(const float* m, v3 p) {
+    return V(fma_(m[0], p.x, fma_(m[1], p.y, fma_(m[2], p.z, m[3]))),
+             fma_(m[4], p.x, fma_(m[5], p.y, fma_(m[6], p.z, m[7]))),
+             fma_(m[8], p.x, fma_(m[9], p.y, fma_(m[10], p.z, m[11]))));
+}
+RTW_DEV v3 xf_vector(const float* m, v3 d) {
+    return V(fma_(m[0], d.x, fma_(m[1], d.y, m[2] * d.z)),
+             fma_(m[4], d.x, fma_(m[5], d.y, m[6] * d.z)),
+             fma_(m[8], d.x, fma_(m[9], d.y, m[10] * d.z)));
+}
+// optixTransformNormalFromObjectToWorldSpace: transpose of the world->object linear part
+RTW_DEV v3 xf_normal(const float* inv, v3 n) {
+    return V(fma_(inv[0], n.x, fma_(inv[4], n.y, inv[8] * n.z)),
+             fma_(inv[1], n.x, fma_(inv[5], n.y, inv[9] * n.z)),
+             fma_(inv[2], n.x, fma_(inv[6], n.y, inv[10] * n.z)));
+}
+
+#define RTW_1_PI_F 0.318309886183790671538f
+#define RTW_PIO2_F 1.57079632679489661923f
+#define RTW_FLT_MAX 3.402823466e+38f
+
+// sin/cos(2*pi*r), r in [0,1) — stands in for sinf/cosf of lib/sampling.cuh:15-22,49-60
+RTW_DEV void sincos2pi(float r, float& s_out, float& c_out) {
+    float t = r * 4.0f;
+    float q = __builtin_floorf(t + 0.5f);
+    float f = t - q;
+    float x = f * RTW_PIO2_F;
+    float x2 = x * x;
+    float sp = fma_(x2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fma_(x2, sp, -1.6666654611e-1f);
+    float s = fma_(x * x2, sp, x);
+    float cp = fma_(x2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fma_(x2, cp, 4.166664568298827e-2f);
+    float c = fma_(x2 * x2, cp, fma_(x2, -0.5f, 1.0f));
+    int qi = ((int)q) & 3;
+    float so = (qi == 0) ? s : (qi == 1) ? c : (qi == 2) ? -s : -c;
+    float co = (qi == 0) ? c : (qi == 1) ? -s : (qi == 2) ? -c : s;
+    s_out = so;
+    c_out = co;
+}
+
+// natural log (Cephes logf) — stands in for logf of geometry/volumeBox.cu:79, volumeSphere.cu:93
+RTW_DEV float log_spec(float x) {
+    if (x == 0.0f) return -__builtin_inff();
+    uint32_t ix = __float_as_uint(x);
+    int e = (int)((ix >> 23) & 255u) - 126;
+    ix = (ix & 0x007fffffu) | 0x3f000000u;
+    float m = __uint_as_float(ix);
+    if (m < 0.707106781186547524f) { e -= 1; m = (m + m) - 1.0f; }
+    else { m = m - 1.0f; }
+    float z = m * m;
+    float y = fma_(7.0376836292e-2f, m, -1.1514610310e-1f);
+    y = fma_(y, m, 1.1676998740e-1f);
+    y = fma_(y, m, -1.2420140846e-1f);
+    y = fma_(y, m, 1.4249322787e-1f);
+    y = fma_(y, m, -1.6668057665e-1f);
+    y = fma_(y, m, 2.0000714765e-1f);
+    y = fma_(y, m, -2.4999993993e-1f);
+    y = fma_(y, m, 3.3333331174e-1f);
+    y = (y * m) * z;
+    float fe = (float)e;
+    y = fma_(-2.12194440e-4f, fe, y);
+    y = fma_(-0.5f, z, y);
+    float r = m + y;
+    r = fma_(0.693359375f, fe, r);
+    return r;
+}
+
+// ------------------------------------------------------------------ RNG
+// lib/random.cuh:7-19 (tea<N>)
+template <unsigned N>
+RTW_DEV uint32_t tea(uint32_t s0, uint32_t s1) {
+    uint32_t t = 0;
+#pragma unroll 4
+    for (unsigned n = 0; n < N; n++) {
+        t += 0x9E3779B9u;
+        s0 += ((s1 << 4) + 0xa341316cu) ^ (s1 + t) ^ ((s1 >> 5) + 0xc8013ea4u);
+        s1 += ((s0 << 4) + 0xad90777du) ^ (s0 + t) ^ ((s0 >> 5) + 0x7e95761eu);
+    }
+    return s0;
+}
+// OptiX SDK cuda/random.h lcg/rnd
+RTW_DEV float lcg_rnd(uint32_t& s) {
+    s = 1664525u * s + 1013904223u;
+    return (float)(s & 0x00FFFFFFu) / (float)0x01000000;
+}
+// lib/random.cuh:22-38 (xorshift32 / randf incl. quirk Q10)
+RTW_DEV float xorshift_randf(uint32_t& s) {
+    s ^= s << 13;
+    s ^= s >> 17;
+    s ^= s << 5;
+    float r = ((float)s) / 4294967296.0f;
+    return (r != 1.0f) ? r : (float)0x3F7FFFFF;
+}
+RTW_DEV void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t (&out)[4]) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0;
+        uint32_t n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+RTW_DEV float u24(uint32_t v) { return (float)(v >> 8) * (1.0f / 16777216.0f); }
+
+// Per-path generator. Streams: 0 raygen seed, 1 prd.seed, 2 rayColor's local seed (ray time).
+// KIND == RTW_RNG_TEA_LCG: a = prd.seed word, b = ray-time word.
+// KIND == RTW_RNG_PHILOX : a = stream-1 draw counter, b unused; ray time is draw `depth` of stream 2.
+template <int KIND>
+struct Rng;
+
+template <>
+struct Rng<RTW_RNG_TEA_LCG> {
+    uint32_t a, b;
+    RTW_DEV void init(uint32_t, uint32_t, uint32_t, uint32_t wa, uint32_t wb) { a = wa; b = wb; }
+    RTW_DEV float next1() { return lcg_rnd(a); }
+    RTW_DEV float randf1() { return xorshift_randf(a); }
+    RTW_DEV float ray_time(uint32_t) { return lcg_rnd(b); }
+};
+
+template <>
+struct Rng<RTW_RNG_PHILOX> {
+    uint32_t a, b;
+    uint32_t key, pixel, sample, cb;
+    uint32_t c[4];
+    RTW_DEV void init(uint32_t k, uint32_t px, uint32_t smp, uint32_t wa, uint32_t wb) {
+        key = k; pixel = px; sample = smp; a = wa; b = wb; cb = 0xffffffffu;
+        c[0] = c[1] = c[2] = c[3] = 0;
+    }
+    RTW_DEV float next1() {
+        uint32_t blk = a >> 2;
+        if (blk != cb) { philox4x32_10(pixel, sample, blk, 1u, key, 0u, c); cb = blk; }
+        uint32_t l = a & 3u;
+        uint32_t v = (l == 0) ? c[0] : (l == 1) ? c[1] : (l == 2) ? c[2] : c[3];
+        a++;
+        return u24(v);
+    }
+    RTW_DEV float randf1() { return next1(); }
+    RTW_DEV float ray_time(uint32_t depth) {
+        uint32_t o[4];
+        philox4x32_10(pixel, sample, depth >> 2, 2u, key, 0u, o);
+        uint32_t l = depth & 3u;
+        return u24((l == 0) ? o[0] : (l == 1) ? o[1] : (l == 2) ? o[2] : o[3]);
+    }
+};
+
+// ------------------------------------------------------------------ device scene
+struct BvhNode {
+    float mn[3];
+    uint32_t left_first;
+    float mx[3];
+    uint32_t count;
+};
+
+// per-primitive shading record baked at upload: material + its (constant) texture colour
+struct Shade {
+    int32_t type;       // rtw_material_type
+    int32_t bsdf_eval;
+    float param;        // fuzz or eta
+    float r, g, b;      // texture/constantTexture.cu:5-10, nullTexture.cu:7-12
+    int32_t pad0, pad1;
+};
+
+struct DScene {
+    const rtw_prim* __restrict__ prims;
+    const rtw_xform* __restrict__ xforms;
+    const Shade* __restrict__ shade;       // indexed by primitive
+    const rtw_light* __restrict__ lights;
+    const BvhNode* __restrict__ nodes;
+    const int32_t* __restrict__ tree_prims;  // leaf entries -> primitive index
+    const int32_t* __restrict__ order;       // candidate order: volumes (index order) then the rest (index order)
+    int32_t n_prims, n_vol, n_tree, n_lights, sky_light, use_bvh, has_motion, pad;
+    rtw_camera cam;
+    rtw_pdf pdf;
+};
+
+RTW_DEV bool is_volume(int type) { return type == RTW_PRIM_VOLUME_BOX || type == RTW_PRIM_VOLUME_SPHERE; }
+
+// Scene tables are immutable for the lifetime of a launch, so they are read through the constant
+// address space: a wave-uniform index then becomes an s_load into SGPRs (scalar cache, no VGPRs,
+// no vector-memory latency), a divergent index an ordinary global_load.
+#define RTW_CONST __attribute__((address_space(4)))
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+RTW_DEV const RTW_CONST T* as_const(const T* p) { return (const RTW_CONST T*)(uint64_t)p; }
+
+RTW_DEV rtw_prim load_prim(const DScene& sc, int i) {
+    const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.prims + i);
+    u32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+    rtw_prim r;
+    r.type = (int)a.x; r.material = (int)a.y; r.xform = (int)a.z; r.flip = (int)a.w;
+    r.p[0] = __uint_as_float(b.x); r.p[1] = __uint_as_float(b.y); r.p[2] = __uint_as_float(b.z); r.p[3] = __uint_as_float(b.w);
+    r.p[4] = __uint_as_float(c.x); r.p[5] = __uint_as_float(c.y); r.p[6] = __uint_as_float(c.z); r.p[7] = __uint_as_float(c.w);
+    r.p[8] = __uint_as_float(d.x); r.p[9] = __uint_as_float(d.y); r.p[10] = __uint_as_float(d.z); r.p[11] = __uint_as_float(d.w);
+    return r;
+}
+struct M34 { float m[12]; };
+RTW_DEV M34 load_m34(const float* p) {
+    const RTW_CONST f32x4* q = (const RTW_CONST f32x4*)(uint64_t)p;
+    f32x4 a = q[0], b = q[1], c = q[2];
+    M34 r;
+    r.m[0] = a.x; r.m[1] = a.y; r.m[2] = a.z; r.m[3] = a.w;
+    r.m[4] = b.x; r.m[5] = b.y; r.m[6] = b.z; r.m[7] = b.w;
+    r.m[8] = c.x; r.m[9] = c.y; r.m[10] = c.z; r.m[11] = c.w;
+    return r;
+}
+RTW_DEV M34 load_xf_m(const DScene& sc, int i) { return load_m34(sc.xforms[i].m); }
+RTW_DEV M34 load_xf_inv(const DScene& sc, int i) { return load_m34(sc.xforms[i].inv); }
+RTW_DEV int load_i32(const int32_t* p) { return *as_const(p); }
+RTW_DEV BvhNode load_node(const DScene& sc, uint32_t i) {
+    const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + i);
+    u32x4 a = q[0], b = q[1];
+    BvhNode n;
+    n.mn[0] = __uint_as_float(a.x); n.mn[1] = __uint_as_float(a.y); n.mn[2] = __uint_as_float(a.z); n.left_first = a.w;
+    n.mx[0] = __uint_as_float(b.x); n.mx[1] = __uint_as_float(b.y); n.mx[2] = __uint_as_float(b.z); n.count = b.w;
+    return n;
+}
+
+// geometry/movingSphere.cu:33-39
+RTW_DEV v3 moving_center(const rtw_prim& pr, float time) {
+    v3 c0 = ld3(&pr.p[0]);
+    float t0 = pr.p[7], t1 = pr.p[8];
+    if (t0 == t1) return c0;
+    v3 c1 = ld3(&pr.p[4]);
+    float u = (time - t0) / (t1 - t0);
+    return vfma(vsub(c1, c0), u, c0);
+}
+
+// geometry/sphere.cu:52-60,93-95
+RTW_DEV bool sphere_roots(v3 o, v3 d, v3 c, float r, float tmin, float tmax, float& t_out) {
+    v3 oc = vsub(o, c);
+    float a = dot3(d, d);
+    float b = dot3(oc, d);
+    float cc = fma_(-r, r, dot3(oc, oc));
+    float disc = fma_(b, b, -(a * cc));
+    if (disc < 0.0f) return false;
+    float sq = __builtin_sqrtf(disc);
+    float t = (-b - sq) / a;
+    if (t < tmax && t > tmin) { t_out = t; return true; }
+    t = (-b + sq) / a;
+    if (t < tmax && t > tmin) { t_out = t; return true; }
+    return false;
+}
+
+// geometry/volumeBox.cu:29-52
+RTW_DEV bool box_boundary(float temp1, float temp2, float tMin, float tMax, float& rec) {
+    if (temp1 > temp2) return false;
+    if (temp1 < tMax && temp1 > tMin) { rec = temp1; return true; }
+    if (temp2 < tMax && temp2 > tMin) { rec = temp2; return true; }
+    return false;
+}
+
+// Object-space ray of primitive pr for world ray (o,d).
+RTW_DEV void object_ray(const DScene& sc, const rtw_prim& pr, v3 o, v3 d, float ray_time, v3& oo, v3& dd, v3& motion) {
+    oo = o; dd = d;
+    if (pr.xform != 0) {
+        M34 inv = load_xf_inv(sc, pr.xform);
+        oo = xf_point(inv.m, o);
+        dd = xf_vector(inv.m, d);
+    }
+    motion = V(0.f, 0.f, 0.f);
+    if (pr.type == RTW_PRIM_MOVING_SPHERE) {
+        // matrix-motion transform translate(lerp(C0,C1,rayTime)), geometry/ioMovingSphere.h:161-203
+        v3 c0 = ld3(&pr.p[0]), c1 = ld3(&pr.p[4]);
+        motion = vfma(vsub(c1, c0), ray_time, c0);
+        oo = vsub(oo, motion);
+    }
+}
+
+// One primitive's intersection program against an object-space ray; true when it reports a hit in (tmin,tmax_cur).
+template <class RNG>
+RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, float tmin, float tmax_cur, float gather_time, RNG& g, float& t_out) {
+    switch (pr.type) {
+    case RTW_PRIM_SPHERE:
+        return sphere_roots(oo, dd, ld3(&pr.p[0]), pr.p[3], tmin, tmax_cur, t_out);
+    case RTW_PRIM_MOVING_SPHERE:
+        return sphere_roots(oo, dd, moving_center(pr, gather_time), pr.p[3], tmin, tmax_cur, t_out);
+    case RTW_PRIM_RECT_X:
+    case RTW_PRIM_RECT_Y:
+    case RTW_PRIM_RECT_Z: {
+        // shaders/aarectx.cu:8-22, aarecty.cu:8-22, aarectz.cu:9-23
+        float ok, dk, oa, da, ob, db;
+        if (pr.type == RTW_PRIM_RECT_X) { ok = oo.x; dk = dd.x; oa = oo.y; da = dd.y; ob = oo.z; db = dd.z; }
+        else if (pr.type == RTW_PRIM_RECT_Y) { ok = oo.y; dk = dd.y; oa = oo.x; da = dd.x; ob = oo.z; db = dd.z; }
+        else { ok = oo.z; dk = dd.z; oa = oo.x; da = dd.x; ob = oo.y; db = dd.y; }
+        float inv = 1.0f / dk;
+        float t = (pr.p[4] - ok) * inv;
+        if (!(t >= tmin && t < tmax_cur)) return false;
+        float a = fma_(t, da, oa);
+        float b = fma_(t, db, ob);
+        if (!(a >= pr.p[0] && a <= pr.p[1] && b >= pr.p[2] && b <= pr.p[3])) return false;
+        t_out = t;
+        return true;
+    }
+    case RTW_PRIM_VOLUME_BOX: {
+        // geometry/volumeBox.cu:55-113 (Q8: EPSILON is the integer 0; Q9: extent is not tested)
+        v3 inv = V(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z);
+        v3 t0 = vmul(vsub(ld3(&pr.p[0]), oo), inv);
+        v3 t1 = vmul(vsub(ld3(&pr.p[3]), oo), inv);
+        float temp1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0.x, t1.x), __builtin_fminf(t0.y, t1.y)), __builtin_fminf(t0.z, t1.z));
+        float temp2 = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0.x, t1.x), __builtin_fmaxf(t0.y, t1.y)), __builtin_fmaxf(t0.z, t1.z));
+        float h1, h2;
+        if (!box_boundary(temp1, temp2, -RTW_FLT_MAX, RTW_FLT_MAX, h1)) return false;
+        if (!box_boundary(temp1, temp2, h1, RTW_FLT_MAX, h2)) return false;
+        if (h1 < tmin) h1 = tmin;
+        if (h2 > tmax_cur) h2 = tmax_cur;
+        if (h1 >= h2) return false;
+        if (h1 < 0.f) h1 = 0.f;
+        float len = length3(dd);
+        float hit_distance = -(1.0f / pr.p[6]) * log_spec(g.randf1());
+        float t = h1 + hit_distance / len;
+        if (!(t >= tmin && t < tmax_cur)) return false;
+        t_out = t;
+        return true;
+    }
+    case RTW_PRIM_VOLUME_SPHERE: {
+        // geometry/volumeSphere.cu:67-127
+        v3 c = ld3(&pr.p[0]);
+        float h1, h2;
+        if (!sphere_roots(oo, dd, c, pr.p[3], -RTW_FLT_MAX, RTW_FLT_MAX, h1)) return false;
+        if (!sphere_roots(oo, dd, c, pr.p[3], h1, RTW_FLT_MAX, h2)) return false;
+        if (h1 < tmin) h1 = tmin;
+        if (h2 > tmax_cur) h2 = tmax_cur;
+        if (h1 >= h2) return false;
+        if (h1 < 0.f) h1 = 0.f;
+        float len = length3(dd);
+        float hit_distance = -(1.0f / pr.p[4]) * log_spec(g.next1());
+        float t = h1 + hit_distance / len;
+        if (!(t >= tmin && t < tmax_cur)) return false;
+        t_out = t;
+        return true;
+    }
+    default:
+        return false;
+    }
+}
+
+// Closest / any hit (optixTraverse at raygen.cu:41-54 and closehit.cu:27-40).
+// Candidate order (observable only through volume RNG draws and exact ties in t): volume
+// primitives in index order, then everything else with ties resolved to the lowest index.
+// stack: this thread's column of the LDS traversal stack (stride = block size).
+template <class RNG, bool ANY_HIT, bool SKIP_VOLUMES>
+RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, float ray_time, float gather_time, RNG& g,
+                      uint32_t* stack, uint32_t stack_stride, float& best_t, int& best_prim) {
+    best_t = tmax;
+    best_prim = -1;
+    if (!sc.use_bvh) {
+        // Small scenes: every lane walks the same candidate list, so primitive records come in
+        // through the scalar cache (SGPR operands) and the object-space ray is rebuilt only when
+        // the instance transform changes.
+        int cur_xf = -1;
+        v3 oo = o, dd = d;
+        int k0 = SKIP_VOLUMES ? sc.n_vol : 0;
+        for (int k = k0; k < sc.n_prims; k++) {
+            int pi = load_i32(sc.order + k);
+            const rtw_prim pr = load_prim(sc, pi);
+            v3 po, pd;
+            if (pr.type == RTW_PRIM_MOVING_SPHERE) {
+                v3 mt;
+                object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+            } else {
+                if (pr.xform != cur_xf) {
+                    cur_xf = pr.xform;
+                    if (cur_xf == 0) { oo = o; dd = d; }
+                    else { M34 inv = load_xf_inv(sc, cur_xf); oo = xf_point(inv.m, o); dd = xf_vector(inv.m, d); }
+                }
+                po = oo; pd = dd;
+            }
+            float t;
+            if (prim_test(pr, po, pd, tmin, best_t, gather_time, g, t)) {
+                best_t = t;
+                best_prim = pi;
+                if (ANY_HIT) return;
+            }
+        }
+        return;
+    }
+    // volumes first, in index order
+    bool best_is_vol = false;
+    if (!SKIP_VOLUMES) {
+        for (int k = 0; k < sc.n_vol; k++) {
+            int pi = load_i32(sc.order + k);
+            const rtw_prim pr = load_prim(sc, pi);
+            v3 po, pd, mt;
+            object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+            float t;
+            if (prim_test(pr, po, pd, tmin, best_t, gather_time, g, t)) {
+                best_t = t;
+                best_prim = pi;
+                best_is_vol = true;
+                if (ANY_HIT) return;
+            }
+        }
+    }
+    if (sc.n_tree <= 0) return;
+    // BVH2, per-lane stack staged in LDS
+    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    int sp = 0;
+    uint32_t node = 0;
+    for (;;) {
+        const BvhNode nd = load_node(sc, node);
+        if (nd.count == 0) {
+            uint32_t child[2] = {nd.left_first, nd.left_first + 1u};
+            float tn[2];
+            bool hit[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const BvhNode ch = load_node(sc, child[c]);
+                float ax = (ch.mn[0] - o.x) * inv.x, bx = (ch.mx[0] - o.x) * inv.x;
+                float ay = (ch.mn[1] - o.y) * inv.y, by = (ch.mx[1] - o.y) * inv.y;
+                float az = (ch.mn[2] - o.z) * inv.z, bz = (ch.mx[2] - o.z) * inv.z;
+                float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
+                float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
+                tn[c] = tnear;
+                hit[c] = tnear <= tfar * 1.00001f;
+            }
+            if (hit[0] && hit[1]) {
+                bool first0 = tn[0] <= tn[1];
+                stack[sp * stack_stride] = first0 ? child[1] : child[0];
+                sp++;
+                node = first0 ? child[0] : child[1];
+                continue;
+            }
+            if (hit[0]) { node = child[0]; continue; }
+            if (hit[1]) { node = child[1]; continue; }
+        } else {
+            for (uint32_t k = 0; k < nd.count; k++) {
+                int pi = load_i32(sc.tree_prims + nd.left_first + k);
+                const rtw_prim pr = load_prim(sc, pi);
+                v3 po, pd, mt;
+                object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+                float t;
+                // tie rule: on equal t the lower primitive index wins (== the oracle's index-order scan)
+                float limit = best_t;
+                if (prim_test(pr, po, pd, tmin, RTW_FLT_MAX, gather_time, g, t)) {
+                    if (t < limit || (t == limit && best_prim >= 0 && !best_is_vol && pi < best_prim)) {
+                        best_is_vol = false;
+                        best_t = t;
+                        best_prim = pi;
+                        if (ANY_HIT) return;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        sp--;
+        node = stack[sp * stack_stride];
+    }
+}
+
+// Attributes of the committed hit (registers 0..7 of optixReportIntersection): world point, shading normal.
+RTW_DEV void hit_attributes(const DScene& sc, int prim, v3 o, v3 d, float t, float ray_time, float gather_time, v3& point, v3& normal) {
+    const rtw_prim pr = load_prim(sc, prim);
+    v3 oo, dd, motion;
+    object_ray(sc, pr, o, d, ray_time, oo, dd, motion);
+    v3 p_obj = vfma(dd, t, oo);
+    bool has_xf = pr.xform != 0;
+    M34 xm, xi;
+    if (has_xf) { xm = load_xf_m(sc, pr.xform); xi = load_xf_inv(sc, pr.xform); }
+    if (pr.type == RTW_PRIM_SPHERE) {
+        // sphere.cu:63-67 (Q13: world point minus object-space centre)
+        v3 pw = has_xf ? xf_point(xm.m, p_obj) : p_obj;
+        v3 n = vscale(vsub(pw, ld3(&pr.p[0])), 1.0f / pr.p[3]);
+        if (has_xf) n = xf_normal(xi.m, n);
+        point = pw; normal = n;
+    } else if (pr.type == RTW_PRIM_MOVING_SPHERE) {
+        // movingSphere.cu:83-85
+        v3 pm = vadd(p_obj, motion);
+        v3 pw = has_xf ? xf_point(xm.m, pm) : pm;
+        v3 n = vscale(vsub(pw, moving_center(pr, gather_time)), 1.0f / pr.p[3]);
+        if (has_xf) n = xf_normal(xi.m, n);
+        point = pw; normal = n;
+    } else {
+        v3 n;
+        if (pr.type == RTW_PRIM_RECT_X) n = V(1.f, 0.f, 0.f);
+        else if (pr.type == RTW_PRIM_RECT_Y) n = V(0.f, 1.f, 0.f);
+        else if (pr.type == RTW_PRIM_RECT_Z) n = V(0.f, 0.f, 1.f);
+        else n = V(1.f, 0.f, 0.f);  // volumes: volumeBox.cu:86-93, volumeSphere.cu:97-105
+        if (pr.flip && !is_volume(pr.type)) n = vneg(n);
+        if (has_xf) {
+            point = xf_point(xm.m, p_obj);
+            normal = normalize3(xf_normal(xi.m, n));
+        } else {
+            point = p_obj;
+            normal = n;
+        }
+    }
+}
+
+// lib/sampling.cuh:25-34
+template <class RNG>
+RTW_DEV v3 random_in_unit_sphere(RNG& g) {
+    v3 p;
+    do {
+        float a = g.next1();
+        float b = g.next1();
+        float c = g.next1();
+        p = V(fma_(2.0f, a, -1.0f), fma_(2.0f, b, -1.0f), fma_(2.0f, c, -1.0f));
+    } while (dot3(p, p) >= 1.0f);
+    return p;
+}
+
+// sutil reflect
+RTW_DEV v3 reflect3(v3 i, v3 n) {
+    float k = -2.0f * dot3(n, i);
+    return vfma(n, k, i);
+}
+
+enum { EV_MISS = 0, EV_HIT = 1, EV_FINISH = 2, EV_CANCEL = 3 };
+
+}  // namespace rtwdev
