@@ -1,0 +1,169 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark: Msamples/s of the Cornell box, 1920x1080 at 4096 spp (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+One process per GPU (torchrun sets RANK/LOCAL_RANK/WORLD_SIZE). A "step" is one full render of the
+metric workload: the framebuffer is split into N row tiles, rank g path-traces rows
+[g*H/N,(g+1)*H/N) for all spp through the C ABI (librtw_hip.so, hand-written HIP), then ONE RCCL
+gather brings the float4 tiles to rank 0. Total work is fixed as N grows ("strong" scaling).
+Rank 0 prints ONE JSON line. torch is plumbing only: device memory, stream, torch.distributed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WIDTH, HEIGHT, SPP, DEPTH, SEED = 1920, 1080, 4096, 50, 0x6314759
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def cpu_baseline(blob, abi):
+    """CPU oracle (oracle/rtw_oracle.c, 'port') on a bounded sample of the same workload: the full
+    1920x1080 frame at depth 50, few spp, timed on this host's cores. Baseline only."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle  # the checker; used here only as the timed CPU baseline
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    # single thread: a 1920x135 band at 1 spp (259k samples), all threads: full frame at 2 spp
+    p1 = abi.make_params(WIDTH, HEIGHT, 1, DEPTH, seed=SEED, row0=472, row1=607)
+    t = time.perf_counter()
+    _, s1 = oracle.render(blob, p1, threads=1)
+    dt1 = time.perf_counter() - t
+    pn = abi.make_params(WIDTH, HEIGHT, 2, DEPTH, seed=SEED)
+    t = time.perf_counter()
+    _, sn = oracle.render(blob, pn, threads=cores)
+    dtn = time.perf_counter() - t
+    return {
+        "value": round(sn.samples / dtn / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
+        "sample": f"Cornell box {WIDTH}x{HEIGHT}, 2 spp, depth {DEPTH}, {cores} threads ({dtn:.1f} s); "
+                  f"single thread: rows 472-606 at 1 spp = {s1.samples / dt1 / 1e6:.4f} Msamples/s ({dt1:.1f} s)",
+        "single_thread_value": round(s1.samples / dt1 / 1e6, 4),
+        "segments_per_sample": round(sn.segments / sn.samples, 4),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (a reduced-spp line is not the headline metric)")
+    ap.add_argument("--rng", type=int, default=0, help="0 Philox4x32-10 (default), 1 the reference's TEA+LCG")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracing_weekend_amd import abi
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    blob = abi.build_scene(0, WIDTH, HEIGHT)
+    rows = [(g * HEIGHT) // world for g in range(world + 1)]
+    row0, row1 = rows[rank], rows[rank + 1]
+    max_rows = max(rows[g + 1] - rows[g] for g in range(world))
+    params = abi.make_params(WIDTH, HEIGHT, args.spp, DEPTH, seed=SEED, row0=row0, row1=row1, rng_kind=args.rng)
+
+    r = abi.Renderer(local_rank)
+    r.upload_scene(blob)
+    tile = torch.zeros((max_rows, WIDTH, 4), dtype=torch.float32, device=dev)
+    gathered = [torch.empty_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+
+    def step():
+        st = r.render_device(params, tile.data_ptr(), stream)
+        if world > 1:
+            dist.gather(tile, gathered, dst=0)  # the one collective: row tiles -> rank 0 over xGMI
+        return st
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    stats = []
+    for _ in range(args.steps):
+        stats.append(step())
+    fence()
+    dt = time.perf_counter() - t0
+
+    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    agg = torch.tensor([float(sum(s.segments for s in stats)), float(sum(s.samples for s in stats)),
+                        float(sum(s.shadow_rays for s in stats))], dtype=torch.float64, device=dev)
+    kt = torch.tensor([sum(s.bounce_seconds for s in stats), float(sum(s.bounce_launches for s in stats)),
+                       sum(s.seconds for s in stats)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    dt_max = float(t.item())
+    segments, samples, shadow = (float(x) for x in agg.tolist())
+
+    if rank == 0:
+        # rank 0's own dominant kernel (k_bounce): algorithmic bytes = 128 B per ray segment it processed
+        # (64 B SoA path state read + written once per segment), time = HIP events recorded on
+        # the launch stream around the bounce-kernel loops inside rtw_render_device.
+        seg0 = float(sum(s.segments for s in stats))
+        b_s, b_n, r_s = (float(x) for x in kt.tolist())
+        achieved = 128.0 * seg0 / b_s / 1e9 if b_s > 0 else 0.0
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                with open(pmc) as f:
+                    traffic = json.load(f).get("k_bounce_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Msamples/s, Cornell box 1920x1080 4096spp",
+            "value": round(samples / dt_max / 1e6, 3),
+            "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_max / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"Cornell box (reference scene 0) {WIDTH}x{HEIGHT}, {args.spp} spp, max depth {DEPTH}, "
+                                   f"NEE mixture PDF (cosine + light rect), RR from depth 2, "
+                                   f"{'Philox4x32-10' if args.rng == 0 else 'TEA+LCG'} seed 0x{SEED:x}",
+                       "partition": f"{world} row tile(s) of {max_rows} rows, one RCCL gather per step" if world > 1 else "single tile",
+                       "segments_per_sample": round(segments / samples, 4),
+                       "shadow_rays_per_sample": round(shadow / samples, 4),
+                       "paths_in_flight": int(os.environ.get("RTW_POOL_PATHS", 1 << 26))},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "kernel": "k_bounce", "launches": int(b_n),
+                         "avg_launch_us": round(b_s / b_n * 1e6, 3) if b_n else None,
+                         "algorithmic_bytes_per_launch": round(128.0 * seg0 / b_n, 1) if b_n else None,
+                         "render_device_seconds_rank0": round(r_s, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(blob, abi)
+        print(json.dumps(line), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

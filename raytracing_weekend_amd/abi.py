@@ -12,7 +12,7 @@ import numpy as np
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 REPO_DIR = os.path.dirname(PKG_DIR)
 HOST_LIB = os.path.join(PKG_DIR, "host", "librtw_host.so")
-HIP_LIB = os.path.join(PKG_DIR, "csrc", "librtw_hip.so")
+HIP_LIB = os.environ.get("RTW_HIP_LIB") or os.path.join(PKG_DIR, "csrc", "librtw_hip.so")
 
 RTW_ABI_VERSION = 1
 RTW_SCENE_MAGIC = 0x57545221

@@ -202,6 +202,21 @@ struct Shade {
     int32_t pad0, pad1;
 };
 
+// Small-scene candidate lists, built at upload (rtw_upload_scene). 32-byte records so that one
+// s_load_dwordx8 brings a whole candidate into SGPRs; rectangles are sorted by axis inside a group so
+// the inner loops contain no per-candidate kind dispatch at all.
+struct BruteGroup {
+    int32_t xform;
+    int32_t first;                 // first record of the group in recs[]
+    int32_t n_rx, n_ry, n_rz, n_sph;
+    int32_t pad0, pad1;
+};
+struct BruteRec {
+    float a, b, c, d, e;           // rect: a0,a1,b0,b1,k   sphere: cx,cy,cz,r,-
+    int32_t prim;
+    int32_t pad0, pad1;
+};
+
 struct DScene {
     const rtw_prim* __restrict__ prims;
     const rtw_xform* __restrict__ xforms;
@@ -210,7 +225,10 @@ struct DScene {
     const BvhNode* __restrict__ nodes;
     const int32_t* __restrict__ tree_prims;  // leaf entries -> primitive index
     const int32_t* __restrict__ order;       // candidate order: volumes (index order) then the rest (index order)
-    int32_t n_prims, n_vol, n_tree, n_lights, sky_light, use_bvh, has_motion, pad;
+    const BruteGroup* __restrict__ groups;   // small scenes: primitives regrouped by instance transform and kind
+    const BruteRec* __restrict__ recs;
+    int32_t n_prims, n_vol, n_tree, n_lights, sky_light, use_bvh, has_motion, n_groups;
+    int32_t n_generic, pad0, pad1, pad2;     // order[n_vol .. n_vol+n_generic): moving spheres, tested through the generic path
     rtw_camera cam;
     rtw_pdf pdf;
 };
@@ -249,6 +267,21 @@ RTW_DEV M34 load_m34(const float* p) {
 RTW_DEV M34 load_xf_m(const DScene& sc, int i) { return load_m34(sc.xforms[i].m); }
 RTW_DEV M34 load_xf_inv(const DScene& sc, int i) { return load_m34(sc.xforms[i].inv); }
 RTW_DEV int load_i32(const int32_t* p) { return *as_const(p); }
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+RTW_DEV BruteGroup load_group(const DScene& sc, int i) {
+    const u32x8 q = *(const RTW_CONST u32x8*)(uint64_t)(sc.groups + i);
+    BruteGroup g;
+    g.xform = (int)q[0]; g.first = (int)q[1]; g.n_rx = (int)q[2]; g.n_ry = (int)q[3]; g.n_rz = (int)q[4]; g.n_sph = (int)q[5];
+    g.pad0 = 0; g.pad1 = 0;
+    return g;
+}
+RTW_DEV BruteRec load_rec(const DScene& sc, int i) {
+    const u32x8 q = *(const RTW_CONST u32x8*)(uint64_t)(sc.recs + i);
+    BruteRec r;
+    r.a = __uint_as_float(q[0]); r.b = __uint_as_float(q[1]); r.c = __uint_as_float(q[2]); r.d = __uint_as_float(q[3]);
+    r.e = __uint_as_float(q[4]); r.prim = (int)q[5]; r.pad0 = 0; r.pad1 = 0;
+    return r;
+}
 RTW_DEV BvhNode load_node(const DScene& sc, uint32_t i) {
     const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + i);
     u32x4 a = q[0], b = q[1];
@@ -310,8 +343,10 @@ RTW_DEV void object_ray(const DScene& sc, const rtw_prim& pr, v3 o, v3 d, float 
 }
 
 // One primitive's intersection program against an object-space ray; true when it reports a hit in (tmin,tmax_cur).
+// inv = (1/dd.x, 1/dd.y, 1/dd.z) by IEEE division: the caller computes it once per object-space ray and
+// reuses it for every rectangle / box under the same transform (same bits as dividing per primitive).
 template <class RNG>
-RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, float tmin, float tmax_cur, float gather_time, RNG& g, float& t_out) {
+RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, v3 inv, float tmin, float tmax_cur, float gather_time, RNG& g, float& t_out) {
     switch (pr.type) {
     case RTW_PRIM_SPHERE:
         return sphere_roots(oo, dd, ld3(&pr.p[0]), pr.p[3], tmin, tmax_cur, t_out);
@@ -321,12 +356,11 @@ RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, float tmin, float tmax_
     case RTW_PRIM_RECT_Y:
     case RTW_PRIM_RECT_Z: {
         // shaders/aarectx.cu:8-22, aarecty.cu:8-22, aarectz.cu:9-23
-        float ok, dk, oa, da, ob, db;
-        if (pr.type == RTW_PRIM_RECT_X) { ok = oo.x; dk = dd.x; oa = oo.y; da = dd.y; ob = oo.z; db = dd.z; }
-        else if (pr.type == RTW_PRIM_RECT_Y) { ok = oo.y; dk = dd.y; oa = oo.x; da = dd.x; ob = oo.z; db = dd.z; }
-        else { ok = oo.z; dk = dd.z; oa = oo.x; da = dd.x; ob = oo.y; db = dd.y; }
-        float inv = 1.0f / dk;
-        float t = (pr.p[4] - ok) * inv;
+        float ok, ik, oa, da, ob, db;
+        if (pr.type == RTW_PRIM_RECT_X) { ok = oo.x; ik = inv.x; oa = oo.y; da = dd.y; ob = oo.z; db = dd.z; }
+        else if (pr.type == RTW_PRIM_RECT_Y) { ok = oo.y; ik = inv.y; oa = oo.x; da = dd.x; ob = oo.z; db = dd.z; }
+        else { ok = oo.z; ik = inv.z; oa = oo.x; da = dd.x; ob = oo.y; db = dd.y; }
+        float t = (pr.p[4] - ok) * ik;
         if (!(t >= tmin && t < tmax_cur)) return false;
         float a = fma_(t, da, oa);
         float b = fma_(t, db, ob);
@@ -336,7 +370,6 @@ RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, float tmin, float tmax_
     }
     case RTW_PRIM_VOLUME_BOX: {
         // geometry/volumeBox.cu:55-113 (Q8: EPSILON is the integer 0; Q9: extent is not tested)
-        v3 inv = V(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z);
         v3 t0 = vmul(vsub(ld3(&pr.p[0]), oo), inv);
         v3 t1 = vmul(vsub(ld3(&pr.p[3]), oo), inv);
         float temp1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0.x, t1.x), __builtin_fminf(t0.y, t1.y)), __builtin_fminf(t0.z, t1.z));
@@ -377,6 +410,9 @@ RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, float tmin, float tmax_
     }
 }
 
+RTW_DEV bool uses_inv(int type) { return type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_VOLUME_BOX; }
+RTW_DEV v3 recip3(v3 d) { return V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+
 // Closest / any hit (optixTraverse at raygen.cu:41-54 and closehit.cu:27-40).
 // Candidate order (observable only through volume RNG draws and exact ties in t): volume
 // primitives in index order, then everything else with ties resolved to the lowest index.
@@ -386,37 +422,6 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
                       uint32_t* stack, uint32_t stack_stride, float& best_t, int& best_prim) {
     best_t = tmax;
     best_prim = -1;
-    if (!sc.use_bvh) {
-        // Small scenes: every lane walks the same candidate list, so primitive records come in
-        // through the scalar cache (SGPR operands) and the object-space ray is rebuilt only when
-        // the instance transform changes.
-        int cur_xf = -1;
-        v3 oo = o, dd = d;
-        int k0 = SKIP_VOLUMES ? sc.n_vol : 0;
-        for (int k = k0; k < sc.n_prims; k++) {
-            int pi = load_i32(sc.order + k);
-            const rtw_prim pr = load_prim(sc, pi);
-            v3 po, pd;
-            if (pr.type == RTW_PRIM_MOVING_SPHERE) {
-                v3 mt;
-                object_ray(sc, pr, o, d, ray_time, po, pd, mt);
-            } else {
-                if (pr.xform != cur_xf) {
-                    cur_xf = pr.xform;
-                    if (cur_xf == 0) { oo = o; dd = d; }
-                    else { M34 inv = load_xf_inv(sc, cur_xf); oo = xf_point(inv.m, o); dd = xf_vector(inv.m, d); }
-                }
-                po = oo; pd = dd;
-            }
-            float t;
-            if (prim_test(pr, po, pd, tmin, best_t, gather_time, g, t)) {
-                best_t = t;
-                best_prim = pi;
-                if (ANY_HIT) return;
-            }
-        }
-        return;
-    }
     // volumes first, in index order
     bool best_is_vol = false;
     if (!SKIP_VOLUMES) {
@@ -426,7 +431,7 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
             v3 po, pd, mt;
             object_ray(sc, pr, o, d, ray_time, po, pd, mt);
             float t;
-            if (prim_test(pr, po, pd, tmin, best_t, gather_time, g, t)) {
+            if (prim_test(pr, po, pd, recip3(pd), tmin, best_t, gather_time, g, t)) {
                 best_t = t;
                 best_prim = pi;
                 best_is_vol = true;
@@ -434,9 +439,60 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
             }
         }
     }
+    // The closest hit is the minimum over (t, primitive index) of the non-volume candidates, which is
+    // what the oracle's index-order scan with a strict '<' yields; written this way the candidates
+    // may be visited in any order, so they are regrouped (brute lists) or culled (BVH) freely.
+#define RTW_ACCEPT(T_, PI_)                                                                          \
+    if ((T_) < best_t || (!ANY_HIT && (T_) == best_t && best_prim >= 0 && !best_is_vol && (PI_) < best_prim)) { \
+        best_t = (T_); best_prim = (PI_); best_is_vol = false;                                       \
+        if (ANY_HIT) return;                                                                         \
+    }
+    if (!sc.use_bvh) {
+        // Small scenes: every lane walks the same candidate lists, so the records arrive through the
+        // scalar cache as SGPR operands. Per instance transform: one object-space ray, one reciprocal
+        // direction, then straight-line tests (rect x / y / z lists, spheres).
+        for (int gi = 0; gi < sc.n_groups; gi++) {
+            const BruteGroup G = load_group(sc, gi);
+            v3 oo = o, dd = d;
+            if (G.xform != 0) { M34 im = load_xf_inv(sc, G.xform); oo = xf_point(im.m, o); dd = xf_vector(im.m, d); }
+            int ri = G.first;
+            if (G.n_rx + G.n_ry + G.n_rz > 0) {
+                const v3 inv = recip3(dd);
+#define RTW_RECT_LOOP(N_, OK_, IK_, OA_, DA_, OB_, DB_)                                              \
+                for (int i = 0; i < (N_); i++, ri++) {                                               \
+                    const BruteRec R = load_rec(sc, ri);                                             \
+                    const float t = (R.e - (OK_)) * (IK_);                                           \
+                    if (!(t >= tmin)) continue;                                                      \
+                    const float a = fma_(t, (DA_), (OA_));                                           \
+                    const float b = fma_(t, (DB_), (OB_));                                           \
+                    if (!(a >= R.a && a <= R.b && b >= R.c && b <= R.d)) continue;                   \
+                    RTW_ACCEPT(t, R.prim)                                                            \
+                }
+                RTW_RECT_LOOP(G.n_rx, oo.x, inv.x, oo.y, dd.y, oo.z, dd.z)   // shaders/aarectx.cu:8-22
+                RTW_RECT_LOOP(G.n_ry, oo.y, inv.y, oo.x, dd.x, oo.z, dd.z)   // shaders/aarecty.cu:8-22
+                RTW_RECT_LOOP(G.n_rz, oo.z, inv.z, oo.x, dd.x, oo.y, dd.y)   // shaders/aarectz.cu:9-23
+#undef RTW_RECT_LOOP
+            }
+            for (int i = 0; i < G.n_sph; i++, ri++) {
+                const BruteRec R = load_rec(sc, ri);
+                float t;
+                if (sphere_roots(oo, dd, V(R.a, R.b, R.c), R.d, tmin, RTW_FLT_MAX, t)) { RTW_ACCEPT(t, R.prim) }
+            }
+        }
+        // moving spheres (own motion transform per candidate): generic path
+        for (int k = 0; k < sc.n_generic; k++) {
+            const int pi = load_i32(sc.order + sc.n_vol + k);
+            const rtw_prim pr = load_prim(sc, pi);
+            v3 po, pd, mt;
+            object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+            float t;
+            if (prim_test(pr, po, pd, V(0.f, 0.f, 0.f), tmin, RTW_FLT_MAX, gather_time, g, t)) { RTW_ACCEPT(t, pi) }
+        }
+        return;
+    }
     if (sc.n_tree <= 0) return;
     // BVH2, per-lane stack staged in LDS
-    v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const v3 inv = recip3(d);
     int sp = 0;
     uint32_t node = 0;
     for (;;) {
@@ -471,23 +527,18 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
                 const rtw_prim pr = load_prim(sc, pi);
                 v3 po, pd, mt;
                 object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+                v3 pinv = inv;
+                if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
                 float t;
                 // tie rule: on equal t the lower primitive index wins (== the oracle's index-order scan)
-                float limit = best_t;
-                if (prim_test(pr, po, pd, tmin, RTW_FLT_MAX, gather_time, g, t)) {
-                    if (t < limit || (t == limit && best_prim >= 0 && !best_is_vol && pi < best_prim)) {
-                        best_is_vol = false;
-                        best_t = t;
-                        best_prim = pi;
-                        if (ANY_HIT) return;
-                    }
-                }
+                if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time, g, t)) { RTW_ACCEPT(t, pi) }
             }
         }
         if (sp == 0) break;
         sp--;
         node = stack[sp * stack_stride];
     }
+#undef RTW_ACCEPT
 }
 
 // Attributes of the committed hit (registers 0..7 of optixReportIntersection): world point, shading normal.

@@ -31,9 +31,12 @@ using namespace rtwdev;
 
 namespace {
 
+#ifndef RTW_MIN_WAVES
+#define RTW_MIN_WAVES 1  // __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow
+#endif
 constexpr int kBlock = 256;                 // 4 wave64 per workgroup
-constexpr uint32_t kChunksPerRegion = 64;   // a region = 64 chunks of 256 paths
-constexpr uint32_t kRegionCap = kChunksPerRegion * kBlock;
+constexpr uint32_t kMinRegionCap = 64 * kBlock;  // a region holds at least 64 chunks of 256 paths
+constexpr uint32_t kMaxRegions = 2048;           // region counters scanned in LDS by every workgroup
 constexpr int kBruteMaxPrims = 24;          // at or below: scalar-cache brute force; above: BVH
 
 struct BounceArgs {
@@ -44,7 +47,7 @@ struct BounceArgs {
     const uint32_t* cnt_in;
     uint32_t* cnt_out;
     unsigned long long* stats;
-    uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, pad;
+    uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, pad;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -52,11 +55,11 @@ struct BounceArgs {
 // (raygen/raygen.cu:36-84, shaders/closehit.cu:45-121, miss/miss.cu:8-30).
 // Returns true when the path continues into the next bounce.
 template <int KIND>
-RTW_DEV bool segment(const BounceArgs& A, Rng<KIND>& g, v3& origin, v3& dir, v3& T, v3& L, float gather_time,
+RTW_DEV bool segment(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, v3& origin, v3& dir, v3& T, v3& L, float gather_time,
                      uint32_t* stack, uint32_t& n_shadow) {
     const DScene& sc = A.sc;
     float ray_time = 0.0f;
-    if (KIND == RTW_RNG_TEA_LCG || sc.has_motion) ray_time = g.ray_time(A.depth);  // raygen.cu:48
+    if (KIND == RTW_RNG_TEA_LCG || sc.has_motion) ray_time = g.ray_time(depth);  // raygen.cu:48
 
     float t;
     int prim;
@@ -223,17 +226,17 @@ RTW_DEV bool segment(const BounceArgs& A, Rng<KIND>& g, v3& origin, v3& dir, v3&
     if (ev != EV_HIT) return false;
     origin = so; dir = sd;
     T = vmul(T, att);
-    if (2u <= A.depth) {  // raygen.cu:74-82
+    if (2u <= depth) {  // raygen.cu:74-82
         float p = __builtin_fmaxf(__builtin_fmaxf(T.x, T.y), T.z);
         if (p < g.next1()) return false;
         T = vscale(T, 1.0f / p);
     }
-    return A.depth + 1u < A.max_depth;
+    return depth + 1u < A.max_depth;
 }
 
 // ---------------------------------------------------------------------------------------------
 template <int KIND, bool FIRST>
-__global__ void __launch_bounds__(kBlock) k_bounce(const BounceArgs A) {
+__global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceArgs A) {
     extern __shared__ uint32_t s_stack[];
     __shared__ uint32_t s_wave[kBlock / 64];
     __shared__ uint32_t s_base;
@@ -242,23 +245,62 @@ __global__ void __launch_bounds__(kBlock) k_bounce(const BounceArgs A) {
     uint32_t* my_stack = s_stack + tid;
     uint32_t n_seg = 0, n_shadow = 0;
 
-    const uint32_t n_items = A.n_regions * kChunksPerRegion;
-    for (uint32_t item = blockIdx.x; item < n_items; item += gridDim.x) {
-        // chunk-major: live chunks (low chunk index) are dealt round-robin to the workgroups
-        const uint32_t region = item % A.n_regions;
-        const uint32_t chunk = item / A.n_regions;
-        uint32_t n_in;
+    // Work list. Region r holds cnt_in[r] live paths = ceil(cnt/256) chunks. Every workgroup scans the
+    // (<= kMaxRegions) counters into an LDS prefix array once, then strides over the virtual chunk
+    // ids: no empty iterations, perfect balance, and a launch with nothing alive costs one scan.
+    __shared__ uint32_t s_pref[kMaxRegions + 1];
+    __shared__ uint32_t s_part[kBlock];
+    uint32_t total_chunks;
+    const uint32_t chunks_per_region = A.region_cap / kBlock;
+    if (FIRST) {
+        total_chunks = (A.n_paths + kBlock - 1) / kBlock;
+    } else {
+        constexpr uint32_t kPer = kMaxRegions / kBlock;
+        uint32_t loc[kPer];
+        uint32_t sum = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) {
+            const uint32_t r = tid * kPer + j;
+            const uint32_t c = r < A.n_regions ? (A.cnt_in[r] + kBlock - 1) / kBlock : 0u;
+            loc[j] = sum;
+            sum += c;
+        }
+        s_part[tid] = sum;
+        __syncthreads();
+        for (uint32_t off = 1; off < kBlock; off <<= 1) {
+            uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+            __syncthreads();
+            s_part[tid] += v;
+            __syncthreads();
+        }
+        const uint32_t excl = s_part[tid] - sum;
+#pragma unroll
+        for (uint32_t j = 0; j < kPer; j++) s_pref[tid * kPer + j] = excl + loc[j];
+        if (tid == kBlock - 1) s_pref[kMaxRegions] = s_part[tid];
+        __syncthreads();
+        total_chunks = s_pref[kMaxRegions];
+    }
+    for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
+        uint32_t region, chunk, n_in;
         if (FIRST) {
-            uint32_t lo = region * kRegionCap;
-            n_in = A.n_paths > lo ? min(kRegionCap, A.n_paths - lo) : 0u;
+            region = vc / chunks_per_region;
+            chunk = vc - region * chunks_per_region;
+            const uint32_t lo = region * A.region_cap;
+            n_in = min(A.region_cap, A.n_paths - lo);
         } else {
+            // largest r with s_pref[r] <= vc
+            uint32_t lo = 0, hi = A.n_regions;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_pref[mid] <= vc) lo = mid; else hi = mid;
+            }
+            region = lo;
+            chunk = vc - s_pref[lo];
             n_in = A.cnt_in[region];
         }
-        const uint32_t base = chunk * kBlock;
-        if (base >= n_in) continue;  // uniform per workgroup
-        const uint32_t idx = base + tid;
+        const uint32_t idx = chunk * kBlock + tid;
         const bool valid = idx < n_in;
-        const size_t slot_in = (size_t)region * kRegionCap + idx;
+        const size_t slot_in = (size_t)region * A.region_cap + idx;
 
         bool alive = false;
         v3 origin = V(0, 0, 0), dir = V(0, 0, 0), T = V(1, 1, 1), L = V(0, 0, 0);
@@ -328,8 +370,15 @@ __global__ void __launch_bounds__(kBlock) k_bounce(const BounceArgs A) {
                 }
                 gather_time = fma_((float)gk * (1.0f / 16777216.0f), A.sc.cam.time1 - A.sc.cam.time0, A.sc.cam.time0);
             }
-            alive = segment<KIND>(A, g, origin, dir, T, L, gather_time, my_stack, n_shadow);
-            n_seg++;
+            // A.n_iter consecutive bounces in registers: 1 for the wide early bounces (compaction after every
+            // segment keeps the lanes full), several for the thin tail, where a launch is latency-bound.
+            uint32_t depth = A.depth;
+            for (uint32_t it = 0; it < A.n_iter; it++) {
+                alive = segment<KIND>(A, depth, g, origin, dir, T, L, gather_time, my_stack, n_shadow);
+                n_seg++;
+                depth++;
+                if (!alive) break;
+            }
             w2 = g.b;
             if (!alive) {
                 // removeNaNs, raygen.cu:17-24
@@ -350,7 +399,7 @@ __global__ void __launch_bounds__(kBlock) k_bounce(const BounceArgs A) {
         }
         __syncthreads();
         if (alive) {
-            const size_t so = (size_t)region * kRegionCap + s_base + s_wave[wave] + before;
+            const size_t so = (size_t)region * A.region_cap + s_base + s_wave[wave] + before;
             A.out0[so] = make_float4(origin.x, origin.y, origin.z, dir.x);
             A.out1[so] = make_float4(dir.y, dir.z, T.x, T.y);
             A.out2[so] = make_float4(T.z, L.x, L.y, L.z);
@@ -496,7 +545,7 @@ size_t pool_target_paths() {
         long long v = atoll(e);
         if (v >= 1024) return (size_t)v;
     }
-    return (size_t)1 << 24;  // 16.7 M paths in flight: 2 GiB of ping-pong state, far past L2/MALL on purpose
+    return (size_t)1 << 26;  // 67 M paths in flight: 9 GiB of ping-pong state + radiance slots (HBM-sized on purpose: long batches amortise the thin tail launches)
 }
 
 template <int KIND, bool FIRST>
@@ -590,11 +639,44 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         }
         shade[i] = s;
     }
+    const bool use_bvh = (int)h.n_prims > kBruteMaxPrims;
+    // order[]: volumes (index order), then -- small scenes only -- the moving spheres, which keep the generic test
     for (uint32_t i = 0; i < h.n_prims; i++) if (rtwbvh::is_volume(prims[i].type)) order.push_back((int32_t)i);
     const int n_vol = (int)order.size();
-    for (uint32_t i = 0; i < h.n_prims; i++) if (!rtwbvh::is_volume(prims[i].type)) order.push_back((int32_t)i);
+    if (!use_bvh)
+        for (uint32_t i = 0; i < h.n_prims; i++) if (prims[i].type == RTW_PRIM_MOVING_SPHERE) order.push_back((int32_t)i);
+    const int n_generic = (int)order.size() - n_vol;
 
-    const bool use_bvh = (int)h.n_prims > kBruteMaxPrims;
+    // small scenes: regroup the remaining primitives by instance transform, rectangles by axis
+    std::vector<BruteGroup> groups;
+    std::vector<BruteRec> recs;
+    if (!use_bvh) {
+        std::vector<int> xf_seen;
+        for (uint32_t i = 0; i < h.n_prims; i++) {
+            const int t = prims[i].type;
+            if (rtwbvh::is_volume(t) || t == RTW_PRIM_MOVING_SPHERE) continue;
+            if (std::find(xf_seen.begin(), xf_seen.end(), prims[i].xform) == xf_seen.end()) xf_seen.push_back(prims[i].xform);
+        }
+        for (int xf : xf_seen) {
+            BruteGroup g{};
+            g.xform = xf;
+            g.first = (int32_t)recs.size();
+            const int kinds[4] = {RTW_PRIM_RECT_X, RTW_PRIM_RECT_Y, RTW_PRIM_RECT_Z, RTW_PRIM_SPHERE};
+            int32_t* counts[4] = {&g.n_rx, &g.n_ry, &g.n_rz, &g.n_sph};
+            for (int k = 0; k < 4; k++)
+                for (uint32_t i = 0; i < h.n_prims; i++) {
+                    const rtw_prim& p = prims[i];
+                    if (p.type != kinds[k] || p.xform != xf) continue;
+                    BruteRec r{};
+                    if (k < 3) { r.a = p.p[0]; r.b = p.p[1]; r.c = p.p[2]; r.d = p.p[3]; r.e = p.p[4]; }
+                    else { r.a = p.p[0]; r.b = p.p[1]; r.c = p.p[2]; r.d = p.p[3]; }
+                    r.prim = (int32_t)i;
+                    recs.push_back(r);
+                    (*counts[k])++;
+                }
+            groups.push_back(g);
+        }
+    }
     rtwbvh::Bvh bvh;
     if (use_bvh) {
         bvh = rtwbvh::build_bvh(prims.data(), h.n_prims, xforms.data());
@@ -610,7 +692,9 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     size_t o_nodes = al(o_lights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
     size_t o_tree = al(o_nodes + std::max<size_t>(1, bvh.nodes.size()) * sizeof(BvhNode));
     size_t o_order = al(o_tree + std::max<size_t>(1, bvh.prim_order.size()) * sizeof(int32_t));
-    size_t total = al(o_order + std::max<size_t>(1, order.size()) * sizeof(int32_t));
+    size_t o_groups = al(o_order + std::max<size_t>(1, order.size()) * sizeof(int32_t));
+    size_t o_recs = al(o_groups + std::max<size_t>(1, groups.size()) * sizeof(BruteGroup));
+    size_t total = al(o_recs + std::max<size_t>(1, recs.size()) * sizeof(BruteRec));
     std::vector<char> stage(total, 0);
     if (!prims.empty()) memcpy(stage.data() + o_prims, prims.data(), prims.size() * sizeof(rtw_prim));
     memcpy(stage.data() + o_xf, xforms.data(), xforms.size() * sizeof(rtw_xform));
@@ -620,6 +704,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!bvh.nodes.empty()) memcpy(stage.data() + o_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
     if (!bvh.prim_order.empty()) memcpy(stage.data() + o_tree, bvh.prim_order.data(), bvh.prim_order.size() * sizeof(int32_t));
     if (!order.empty()) memcpy(stage.data() + o_order, order.data(), order.size() * sizeof(int32_t));
+    if (!groups.empty()) memcpy(stage.data() + o_groups, groups.data(), groups.size() * sizeof(BruteGroup));
+    if (!recs.empty()) memcpy(stage.data() + o_recs, recs.data(), recs.size() * sizeof(BruteRec));
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -636,6 +722,10 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.nodes = (const BvhNode*)(d + o_nodes);
     sc.tree_prims = (const int32_t*)(d + o_tree);
     sc.order = (const int32_t*)(d + o_order);
+    sc.groups = (const BruteGroup*)(d + o_groups);
+    sc.recs = (const BruteRec*)(d + o_recs);
+    sc.n_groups = (int)groups.size();
+    sc.n_generic = n_generic;
     sc.n_prims = (int)h.n_prims;
     sc.n_vol = n_vol;
     sc.n_tree = (int)bvh.prim_order.size();
@@ -673,9 +763,27 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     S = std::min<size_t>(S, (size_t)P->spp);
     while (S > 1 && npix * S > 0xfffffff0ull) S--;
     const size_t paths_max = npix * S;
-    const uint32_t regions_max = (uint32_t)((paths_max + kRegionCap - 1) / kRegionCap);
-    const size_t cnt_words = (size_t)regions_max * (size_t)(P->max_depth + 2);
-    int rc = ensure_pool(c, (size_t)regions_max * kRegionCap, npix, cnt_words);
+    // region capacity: a multiple of 256 paths, at least 16384, large enough that <= kMaxRegions regions cover the pool
+    size_t region_cap = std::max<size_t>(kMinRegionCap, (((paths_max + kMaxRegions - 1) / kMaxRegions) + kBlock - 1) / kBlock * kBlock);
+    const uint32_t regions_max = (uint32_t)((paths_max + region_cap - 1) / region_cap);
+    // launch schedule: (first depth, bounces in registers). Early bounces one per launch; the tail in growing groups.
+    std::vector<std::pair<int, int>> sched;
+    {
+        const char* e = getenv("RTW_TAIL_START");
+        const int tail_start = (e && *e) ? std::max(1, atoi(e)) : 4;
+        int d = 0, grp = 2, rep = 0;
+        while (d < P->max_depth) {
+            int n = 1;
+            if (d >= tail_start) {
+                n = std::min(grp, P->max_depth - d);
+                if (++rep == 2) { rep = 0; grp += grp / 2; }
+            }
+            sched.push_back({d, n});
+            d += n;
+        }
+    }
+    const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
+    int rc = ensure_pool(c, (size_t)regions_max * region_cap, npix, cnt_words);
     if (rc) return rc;
 
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
@@ -706,8 +814,8 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         for (size_t s0 = 0; s0 < (size_t)P->spp; s0 += S) {
             const size_t Sb = std::min(S, (size_t)P->spp - s0);
             const size_t paths = npix * Sb;
-            const uint32_t regions = (uint32_t)((paths + kRegionCap - 1) / kRegionCap);
-            HIP_TRY_C(hipMemsetAsync(c->cnt, 0, (size_t)regions * (size_t)(P->max_depth + 2) * sizeof(uint32_t), s));
+            const uint32_t regions = (uint32_t)((paths + region_cap - 1) / region_cap);
+            HIP_TRY_C(hipMemsetAsync(c->cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), s));
             BounceArgs a{};
             a.sc = c->sc;
             a.lbuf = c->lbuf;
@@ -722,21 +830,24 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             a.seed = P->seed;
             a.max_depth = (uint32_t)P->max_depth;
             a.stack_stride = kBlock;
-            const uint32_t n_items = regions * kChunksPerRegion;
-            const int grid = (int)std::min<uint32_t>(n_items, (uint32_t)c->n_cu * 8u);
+            a.region_cap = (uint32_t)region_cap;
+            const uint32_t n_chunks = (uint32_t)((paths + kBlock - 1) / kBlock);
+            const int grid = (int)std::min<uint32_t>(n_chunks, (uint32_t)c->n_cu * 8u);
             hipEvent_t e0 = nullptr, e1 = nullptr;
             HIP_TRY_C(hipEventCreate(&e0));
             ev_loop.push_back(e0);
             HIP_TRY_C(hipEventCreate(&e1));
             ev_loop.push_back(e1);
             HIP_TRY_C(hipEventRecord(e0, s));
-            for (int d = 0; d < P->max_depth; d++) {
-                const int ib = d & 1, ob = ib ^ 1;  // bounce d reads buffer d&1 (bounce 0 reads nothing), writes the other
+            for (size_t li = 0; li < sched.size(); li++) {
+                const int d = sched[li].first;
+                const int ib = (int)(li & 1), ob = ib ^ 1;  // launch li reads buffer li&1 (launch 0 reads nothing), writes the other
                 a.in0 = c->planes[ib][0]; a.in1 = c->planes[ib][1]; a.in2 = c->planes[ib][2]; a.in3 = c->plane3[ib];
                 a.out0 = c->planes[ob][0]; a.out1 = c->planes[ob][1]; a.out2 = c->planes[ob][2]; a.out3 = c->plane3[ob];
-                a.cnt_in = c->cnt + (size_t)d * regions;
-                a.cnt_out = c->cnt + (size_t)(d + 1) * regions;
+                a.cnt_in = c->cnt + li * regions;
+                a.cnt_out = c->cnt + (li + 1) * regions;
                 a.depth = (uint32_t)d;
+                a.n_iter = (uint32_t)sched[li].second;
                 if (P->rng_kind == RTW_RNG_PHILOX) {
                     if (d == 0) launch_bounce<RTW_RNG_PHILOX, true>(a, grid, lds, s);
                     else launch_bounce<RTW_RNG_PHILOX, false>(a, grid, lds, s);
