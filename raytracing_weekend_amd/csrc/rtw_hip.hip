@@ -47,24 +47,28 @@ struct BounceArgs {
     const uint32_t* cnt_in;
     uint32_t* cnt_out;
     unsigned long long* stats;
-    uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, pad;
+    uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, regroup, ablate, pad1;
 };
 
 // ---------------------------------------------------------------------------------------------
 // One path segment: optixTraverse + closest-hit / miss + the tail of rayColor's loop body
 // (raygen/raygen.cu:36-84, shaders/closehit.cu:45-121, miss/miss.cu:8-30).
 // Returns true when the path continues into the next bounce.
+// Stage 1 of a segment: the radiance ray's closest hit (optixTraverse, raygen.cu:41-54).
 template <int KIND>
-RTW_DEV bool segment(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, v3& origin, v3& dir, v3& T, v3& L, float gather_time,
-                     uint32_t* stack, uint32_t& n_shadow) {
+RTW_DEV void trace_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, const v3 origin, const v3 dir, float gather_time,
+                         uint32_t* stack, float& t, int& prim, float& ray_time) {
     const DScene& sc = A.sc;
-    float ray_time = 0.0f;
+    ray_time = 0.0f;
     if (KIND == RTW_RNG_TEA_LCG || sc.has_motion) ray_time = g.ray_time(depth);  // raygen.cu:48
-
-    float t;
-    int prim;
     traverse<Rng<KIND>, false, false>(sc, origin, dir, 1e-6f, 1.e27f, ray_time, gather_time, g, stack, A.stack_stride, t, prim);
+}
 
+// Stage 2: closest-hit / miss programs + the tail of rayColor's loop body.
+template <int KIND>
+RTW_DEV bool shade_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, v3& origin, v3& dir, v3& T, v3& L, float gather_time,
+                         uint32_t* stack, uint32_t& n_shadow, const float t, const int prim, const float ray_time) {
+    const DScene& sc = A.sc;
     v3 radiance = V(0.f, 0.f, 0.f);
     int ev;
     v3 att = V(0.f, 0.f, 0.f), so = origin, sd = dir;
@@ -78,8 +82,9 @@ RTW_DEV bool segment(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, v3
         ev = EV_MISS;
     } else {
         v3 hp, hn;
-        hit_attributes(sc, prim, origin, dir, t, ray_time, gather_time, hp, hn);
-        const RTW_CONST Shade* shp = as_const(sc.shade + prim);
+        if (A.ablate & 1u) { hp = vfma(dir, t, origin); hn = V(0.f, 1.f, 0.f); }
+        else hit_attributes(sc, prim, origin, dir, t, ray_time, gather_time, hp, hn);
+        const RTW_CONST Shade* shp = as_const(sc.shade + ((A.ablate & 2u) ? 1 : prim));
         const int mtype = shp->type;
         const float mparam = shp->param;
         const v3 tex = V(shp->r, shp->g, shp->b);
@@ -206,7 +211,7 @@ RTW_DEV bool segment(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, v3
                 v3 f = vscale(att, RTW_1_PI_F);
                 float ndl = dot3(ldir, hn);
                 float bpdf = __builtin_fmaxf(0.0f, ndl * RTW_1_PI_F);
-                if (0.0f < bpdf && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f)) {
+                if (0.0f < bpdf && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f) && !(A.ablate & 4u)) {
                     const float eps = 500 * 1.0e-7f;
                     float st;
                     int sprim;
@@ -238,8 +243,8 @@ RTW_DEV bool segment(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, v3
 template <int KIND, bool FIRST>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceArgs A) {
     extern __shared__ uint32_t s_stack[];
-    __shared__ uint32_t s_wave[kBlock / 64];
-    __shared__ uint32_t s_base;
+    __shared__ uint32_t s_kcnt[8][kBlock / 64];
+    __shared__ uint32_t s_rec[19][kBlock];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t* my_stack = s_stack + tid;
@@ -304,14 +309,15 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceAr
 
         bool alive = false;
         v3 origin = V(0, 0, 0), dir = V(0, 0, 0), T = V(1, 1, 1), L = V(0, 0, 0);
-        uint32_t w0 = 0, w2 = 0, gk = 0, path_id = 0;
+        uint32_t w0 = 0, gk = 0;
+        float valid_gather = 0.f;
         Rng<KIND> g;
         g.init(A.seed, 0, 0, 0, 0);
         if (valid) {
             float gather_time;
             if (FIRST) {
                 // __raygen__Program (raygen.cu:123-147) + perspectiveCamera (camera.cu:11-19) + color() (raygen.cu:89-95)
-                path_id = (uint32_t)slot_in;
+                const uint32_t path_id = (uint32_t)slot_in;
                 const uint32_t slot = path_id / A.npix;
                 const uint32_t pl = path_id - slot * A.npix;
                 const uint32_t yl = pl / A.width;
@@ -360,52 +366,102 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceAr
                 T = V(p1.z, p1.w, p2.x);
                 L = V(p2.y, p2.z, p2.w);
                 w0 = p3.x; gk = p3.w;
-                if (KIND == RTW_RNG_TEA_LCG) {
-                    path_id = w0;
-                    g.init(A.seed, 0, 0, p3.y, p3.z);
-                } else {
-                    const uint32_t sample = p3.z;
-                    path_id = (sample - A.sample0) * A.npix + (w0 - A.row0 * A.width);
-                    g.init(A.seed, w0, sample, p3.y, sample);
-                }
+                if (KIND == RTW_RNG_TEA_LCG) g.init(A.seed, 0, 0, p3.y, p3.z);
+                else g.init(A.seed, w0, p3.z, p3.y, p3.z);  // word 2 carries the sample index
                 gather_time = fma_((float)gk * (1.0f / 16777216.0f), A.sc.cam.time1 - A.sc.cam.time0, A.sc.cam.time0);
             }
-            // A.n_iter consecutive bounces in registers: 1 for the wide early bounces (compaction after every
-            // segment keeps the lanes full), several for the thin tail, where a launch is latency-bound.
+            valid_gather = gather_time;
+        }
+        float gather_time = valid_gather;
+        bool live = valid;
+        if (A.regroup) {
+            // ---- wide launches: trace, then re-deal the 256 paths of this chunk to lanes by the material
+            // they hit, so that each wave shades (and light-samples, and shadow-traces) one kind of surface.
+            float t = 0.f, ray_time = 0.f;
+            int prim = -1;
+            uint32_t key = 7u;  // idle lane
+            if (valid) {
+                trace_stage<KIND>(A, A.depth, g, origin, dir, gather_time, my_stack, t, prim, ray_time);
+                key = prim < 0 ? 6u : (uint32_t)as_const(A.sc.shade + prim)->type;
+            }
+            uint32_t rank = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const unsigned long long b = __ballot(key == k);
+                if (key == k) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
+                if (lane == 0) s_kcnt[k][wave] = (uint32_t)__popcll(b);
+            }
+            __syncthreads();
+            uint32_t dest = rank, n_live = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+#pragma unroll
+                for (uint32_t w = 0; w < kBlock / 64; w++) {
+                    const uint32_t c = s_kcnt[k][w];
+                    if (k < key || (k == key && w < wave)) dest += c;
+                    if (k < 7) n_live += c;
+                }
+            }
+            s_rec[0][dest] = __float_as_uint(origin.x); s_rec[1][dest] = __float_as_uint(origin.y); s_rec[2][dest] = __float_as_uint(origin.z);
+            s_rec[3][dest] = __float_as_uint(dir.x); s_rec[4][dest] = __float_as_uint(dir.y); s_rec[5][dest] = __float_as_uint(dir.z);
+            s_rec[6][dest] = __float_as_uint(T.x); s_rec[7][dest] = __float_as_uint(T.y); s_rec[8][dest] = __float_as_uint(T.z);
+            s_rec[9][dest] = __float_as_uint(L.x); s_rec[10][dest] = __float_as_uint(L.y); s_rec[11][dest] = __float_as_uint(L.z);
+            s_rec[12][dest] = w0; s_rec[13][dest] = g.a; s_rec[14][dest] = g.b; s_rec[15][dest] = gk;
+            s_rec[16][dest] = __float_as_uint(t); s_rec[17][dest] = (uint32_t)prim; s_rec[18][dest] = __float_as_uint(ray_time);
+            __syncthreads();
+            origin = V(__uint_as_float(s_rec[0][tid]), __uint_as_float(s_rec[1][tid]), __uint_as_float(s_rec[2][tid]));
+            dir = V(__uint_as_float(s_rec[3][tid]), __uint_as_float(s_rec[4][tid]), __uint_as_float(s_rec[5][tid]));
+            T = V(__uint_as_float(s_rec[6][tid]), __uint_as_float(s_rec[7][tid]), __uint_as_float(s_rec[8][tid]));
+            L = V(__uint_as_float(s_rec[9][tid]), __uint_as_float(s_rec[10][tid]), __uint_as_float(s_rec[11][tid]));
+            w0 = s_rec[12][tid];
+            const uint32_t ra = s_rec[13][tid], rb = s_rec[14][tid];
+            gk = s_rec[15][tid];
+            t = __uint_as_float(s_rec[16][tid]); prim = (int)s_rec[17][tid]; ray_time = __uint_as_float(s_rec[18][tid]);
+            __syncthreads();  // s_rec / s_kcnt are reused by the next chunk
+            live = tid < n_live;
+            if (KIND == RTW_RNG_TEA_LCG) g.init(A.seed, 0, 0, ra, rb);
+            else g.init(A.seed, w0, rb, ra, rb);
+            gather_time = fma_((float)gk * (1.0f / 16777216.0f), A.sc.cam.time1 - A.sc.cam.time0, A.sc.cam.time0);
+            if (live) {
+                alive = shade_stage<KIND>(A, A.depth, g, origin, dir, T, L, gather_time, my_stack, n_shadow, t, prim, ray_time);
+                n_seg++;
+            }
+        } else if (valid) {
+            // ---- thin tail launches: A.n_iter consecutive bounces in registers (a launch with few paths is
+            // latency-bound, so fewer, longer launches win; lane order does not matter there).
             uint32_t depth = A.depth;
             for (uint32_t it = 0; it < A.n_iter; it++) {
-                alive = segment<KIND>(A, depth, g, origin, dir, T, L, gather_time, my_stack, n_shadow);
+                float t, ray_time;
+                int prim;
+                trace_stage<KIND>(A, depth, g, origin, dir, gather_time, my_stack, t, prim, ray_time);
+                alive = shade_stage<KIND>(A, depth, g, origin, dir, T, L, gather_time, my_stack, n_shadow, t, prim, ray_time);
                 n_seg++;
                 depth++;
                 if (!alive) break;
             }
-            w2 = g.b;
-            if (!alive) {
-                // removeNaNs, raygen.cu:17-24
-                float lx = (L.x == L.x) ? L.x : 0.f, ly = (L.y == L.y) ? L.y : 0.f, lz = (L.z == L.z) ? L.z : 0.f;
-                A.lbuf[path_id] = make_float4(lx, ly, lz, 0.f);
+        }
+        if (live && !alive) {
+            uint32_t path_id = w0;
+            if (KIND == RTW_RNG_PHILOX) path_id = (g.b - A.sample0) * A.npix + (w0 - A.row0 * A.width);
+            // removeNaNs, raygen.cu:17-24
+            float lx = (L.x == L.x) ? L.x : 0.f, ly = (L.y == L.y) ? L.y : 0.f, lz = (L.z == L.z) ? L.z : 0.f;
+            A.lbuf[path_id] = make_float4(lx, ly, lz, 0.f);
+        }
+        // wave64 ballot + popcount prefix; one atomic per wave reserves its slice of the region's output
+        const unsigned long long ballot = __ballot(alive);
+        if (ballot) {
+            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(&A.cnt_out[region], (uint32_t)__popcll(ballot));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (alive) {
+                const size_t so = (size_t)region * A.region_cap + base + before;
+                A.out0[so] = make_float4(origin.x, origin.y, origin.z, dir.x);
+                A.out1[so] = make_float4(dir.y, dir.z, T.x, T.y);
+                A.out2[so] = make_float4(T.z, L.x, L.y, L.z);
+                A.out3[so] = make_uint4(w0, g.a, g.b, gk);
             }
         }
-        // wave64 ballot + popcount prefix, one atomic per workgroup into this region's counter
-        const unsigned long long ballot = __ballot(alive);
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-        if (lane == 0) s_wave[wave] = (uint32_t)__popcll(ballot);
-        __syncthreads();
-        if (tid == 0) {
-            uint32_t tot = 0;
-#pragma unroll
-            for (int w = 0; w < kBlock / 64; w++) { uint32_t c = s_wave[w]; s_wave[w] = tot; tot += c; }
-            s_base = tot ? atomicAdd(&A.cnt_out[region], tot) : 0u;
-        }
-        __syncthreads();
-        if (alive) {
-            const size_t so = (size_t)region * A.region_cap + s_base + s_wave[wave] + before;
-            A.out0[so] = make_float4(origin.x, origin.y, origin.z, dir.x);
-            A.out1[so] = make_float4(dir.y, dir.z, T.x, T.y);
-            A.out2[so] = make_float4(T.z, L.x, L.y, L.z);
-            A.out3[so] = make_uint4(w0, g.a, w2, gk);
-        }
-        __syncthreads();
     }
     // statistics: wave reduction, one atomic pair per wave
     for (int off = 32; off > 0; off >>= 1) {
@@ -783,6 +839,10 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         }
     }
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
+    const char* rg_env = getenv("RTW_REGROUP");
+    const bool regroup_on = (rg_env && rg_env[0] == '1');
+    const char* ab_env = getenv("RTW_ABLATE");  // timing experiments only: breaks the image on purpose
+    const uint32_t ablate = ab_env ? (uint32_t)atoi(ab_env) : 0u;
     int rc = ensure_pool(c, (size_t)regions_max * region_cap, npix, cnt_words);
     if (rc) return rc;
 
@@ -848,6 +908,8 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
                 a.cnt_out = c->cnt + (li + 1) * regions;
                 a.depth = (uint32_t)d;
                 a.n_iter = (uint32_t)sched[li].second;
+                a.regroup = (a.n_iter == 1 && regroup_on) ? 1u : 0u;
+                a.ablate = ablate;
                 if (P->rng_kind == RTW_RNG_PHILOX) {
                     if (d == 0) launch_bounce<RTW_RNG_PHILOX, true>(a, grid, lds, s);
                     else launch_bounce<RTW_RNG_PHILOX, false>(a, grid, lds, s);

@@ -1,0 +1,46 @@
+// Director.h — host driver with the reference's public surface (RestOfLife/Director.h:115-126):
+//   init / createScene / renderFrame / printPPM / destroy.
+// Everything OptiX inside the reference's Director (context, 26 modules, 36 program groups, pipeline,
+// SBT, launch params, denoiser) is replaced by calls into the C ABI of include/rtw.h.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/rtw.h"
+#include "ioScene.h"
+
+class Director {
+public:
+    Director(bool verbose, bool debug) : _verbose(verbose), _debug(debug) {}
+
+    void init(unsigned int width, unsigned int height, unsigned int samples);
+    void destroy();
+
+    void createScene(unsigned int sceneNumber);
+    void renderFrame();
+    void printPPM();
+
+    // additions over the reference (its depth is hard-wired to 20 at Director.cpp:42, its RNG to tea+lcg)
+    void setMaxDepth(int depth) { m_maxRayDepth = depth; }
+    void setSeed(uint32_t seed) { m_seed = seed; }
+    void setRngKind(int kind) { m_rngKind = kind; }
+    void setDevice(int device) { m_device = device; }
+    const rtw_stats& stats() const { return m_stats; }
+    const std::vector<float>& hostBuffer() const { return m_hostBuffer; }  // linear RGBA, row 0 = bottom row
+
+private:
+    void marshalAndUpload();  // createSBT + initLaunchParams of the reference
+
+    int m_Nx = 0, m_Ny = 0, m_Ns = 0;
+    int m_maxRayDepth = 20;
+    uint32_t m_seed = 0x6314759u;
+    int m_rngKind = RTW_RNG_PHILOX;
+    int m_device = 0;
+    rtw_ctx* m_ctx = nullptr;
+    rtwhost::ioScene m_scene;
+    std::vector<float> m_hostBuffer;
+    rtw_stats m_stats{};
+    bool _verbose = false;
+    bool _debug = false;
+};

@@ -1,0 +1,110 @@
+// main.cpp — command-line front end, same flow and flags as the reference (RestOfLife/main.cpp:29-165):
+//   -s scene  -ns samples  -dx width  -dy height  -h  -v  -g
+// plus what the benchmark configurations need and the reference hard-wires:
+//   -d depth (reference: 20, Director.cpp:42)   -seed N   -rng philox|lcg   -gpu id
+// The reference's resolution / sample clamps (main.cpp:21-27) are widened so that 200x200 and
+// 7680x4320 are reachable, and its scene range bug (only scene 4 selectable, main.cpp:69) is not kept.
+#include <chrono>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+
+#include "Director.h"
+#include "InputParser.h"
+
+#define Nx_MIN (16)
+#define Ny_MIN (16)
+#define Nx_MAX (16384)
+#define Ny_MAX (16384)
+#define Nscene_MAX (4)
+#define Ns_MAX (1024 * 1024)
+
+namespace {
+// parse an integer option; returns false (and leaves `out`) when absent or malformed
+bool intOption(const InputParser& in, const char* flag, const char* what, int& out) {
+    const std::string& v = in.getCmdOption(flag);
+    if (v.empty()) return false;
+    try {
+        out = std::stoi(v, nullptr, 0);
+        return true;
+    } catch (const std::exception&) {
+        std::cerr << "Invalid " << what << ": " << v << std::endl;
+        return false;
+    }
+}
+int clampWarn(const char* what, int x, int lo, int hi) {
+    if (x >= lo && x <= hi) return x;
+    int y = x < lo ? lo : hi;
+    std::cerr << "WARNING: " << what << " " << x << " out of range. Using a value of " << y << std::endl;
+    return y;
+}
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    int Nx = 1200, Ny = 600, Nscene = 0, Ns = 20, depth = 20, gpu = 0;
+    uint32_t seed = 0x6314759u;
+    int rng = RTW_RNG_PHILOX;
+
+    InputParser cl_input(argc, argv);
+    if (cl_input.cmdOptionExists("-h") || cl_input.cmdOptionExists("--help")) {
+        std::cerr << "\n HELP - " << argv[0] << "\n"
+                  << R"(
+    -s N           Scene Selection number N (0 Cornell box, 1 moving spheres, 3 Cornell box with volumes)
+    -ns N          Sample each pixel N times (N: 1, 2, etc.)
+    -dx Nx         Output image width (x dimension)
+    -dy Ny         Output image height (y dimension)
+    -d N           Maximum path depth (reference: 20)
+    -seed N        RNG seed
+    -rng K         philox (default) or lcg (the reference's tea+lcg generator)
+    -gpu N         Device ordinal
+
+    -h             This help message.
+    -v             Verbose output.
+    -g             Debug output.
+
+)";
+        return EXIT_SUCCESS;
+    }
+    const bool Qverbose = cl_input.cmdOptionExists("-v");
+    const bool Qdebug = cl_input.cmdOptionExists("-g");
+
+    int x;
+    if (intOption(cl_input, "-s", "scene number", x)) {
+        if (x >= 0 && x <= Nscene_MAX) Nscene = x;
+        else {
+            std::cerr << "WARNING: Scene number " << x << " out of range. Maximum scene number: " << Nscene_MAX << std::endl;
+            std::cerr << "WARNING: Using a scene value of " << Nscene << std::endl;
+        }
+    }
+    if (intOption(cl_input, "-ns", "number of samples", x)) Ns = clampWarn("Number of samples", x, 1, Ns_MAX);
+    if (intOption(cl_input, "-dx", "image width (-dx)", x)) Nx = clampWarn("Width (-dx)", x, Nx_MIN, Nx_MAX);
+    if (intOption(cl_input, "-dy", "image height (-dy)", x)) Ny = clampWarn("Height (-dy)", x, Ny_MIN, Ny_MAX);
+    if (intOption(cl_input, "-d", "depth (-d)", x)) depth = clampWarn("Depth (-d)", x, 1, 1 << 20);
+    if (intOption(cl_input, "-gpu", "device (-gpu)", x)) gpu = x;
+    if (intOption(cl_input, "-seed", "seed", x)) seed = static_cast<uint32_t>(x);
+    const std::string& rngName = cl_input.getCmdOption("-rng");
+    if (rngName == "lcg") rng = RTW_RNG_TEA_LCG;
+    else if (!rngName.empty() && rngName != "philox") std::cerr << "WARNING: unknown -rng " << rngName << ", using philox" << std::endl;
+
+    Director director(Qverbose, Qdebug);
+    director.setDevice(gpu);
+    director.setMaxDepth(depth);
+    director.setSeed(seed);
+    director.setRngKind(rng);
+
+    auto start = std::chrono::system_clock::now();
+    director.init(Nx, Ny, Ns);
+    if (Qverbose) {
+        std::cerr << "INFO: Output image dimensions: " << Nx << 'x' << Ny << std::endl;
+        std::cerr << "INFO: Number of rays sent per pixel: " << Ns << std::endl;
+        std::cerr << "INFO: Scene number selected: " << Nscene << std::endl;
+    }
+    director.createScene(Nscene);
+    director.renderFrame();
+    auto stop = std::chrono::system_clock::now();
+    std::cerr << "INFO: Took " << std::chrono::duration<float>(stop - start).count() << " seconds." << std::endl;
+
+    director.printPPM();
+    director.destroy();
+    return EXIT_SUCCESS;
+}
