@@ -405,27 +405,27 @@ static void traverse(const scene_t* sc, v3 o, v3 d, float tmin, float tmax, floa
 }
 
 /* Attributes of the committed hit: world point, shading normal (what the IS programs pass through
- * optixReportIntersection registers 0..7). u,v are not produced: only constant/null textures are in scope. */
-static void hit_attributes(const scene_t* sc, const hit_t* h, v3* point, v3* normal) {
+ * optixReportIntersection registers 0..7). u,v are not produced: only constant/null textures are in scope.
+ * The world point is the world ray evaluated at t — the same real point as the reference's
+ * optixTransformPointFromObjectToWorldSpace(o_obj + t*d_obj), without the round trip through object space. */
+static void hit_attributes(const scene_t* sc, const hit_t* h, v3 o, v3 d, v3* point, v3* normal) {
     const rtw_prim* pr = &sc->prims[h->prim];
     const rtw_xform* xf = &sc->xforms[pr->xform];
-    v3 p_obj = vfma(h->d_obj, h->t, h->o_obj);
+    v3 pw = vfma(d, h->t, o);
+    *point = pw;
     switch (pr->type) {
     case RTW_PRIM_SPHERE: {
         /* sphere.cu:63-67: normal from the WORLD point and the OBJECT-space centre (quirk Q13) */
-        v3 pw = (pr->xform != 0) ? xf_point(xf->m, p_obj) : p_obj;
         v3 n = vscale(vsub(pw, ld3(&pr->p[0])), 1.0f / pr->p[3]);
         if (pr->xform != 0) n = xf_normal(xf->inv, n);
-        *point = pw; *normal = n;
+        *normal = n;
         break;
     }
     case RTW_PRIM_MOVING_SPHERE: {
         /* movingSphere.cu:83-85: world point includes the motion translation, centre does not */
-        v3 pm = vadd(p_obj, h->motion);
-        v3 pw = (pr->xform != 0) ? xf_point(xf->m, pm) : pm;
         v3 n = vscale(vsub(pw, h->xcenter), 1.0f / pr->p[3]);
         if (pr->xform != 0) n = xf_normal(xf->inv, n);
-        *point = pw; *normal = n;
+        *normal = n;
         break;
     }
     case RTW_PRIM_RECT_X:
@@ -433,24 +433,12 @@ static void hit_attributes(const scene_t* sc, const hit_t* h, v3* point, v3* nor
     case RTW_PRIM_RECT_Z: {
         v3 n = (pr->type == RTW_PRIM_RECT_X) ? V(1.f, 0.f, 0.f) : (pr->type == RTW_PRIM_RECT_Y) ? V(0.f, 1.f, 0.f) : V(0.f, 0.f, 1.f);
         if (pr->flip) n = vneg(n);
-        if (pr->xform != 0) {
-            *point = xf_point(xf->m, p_obj);
-            *normal = normalize3(xf_normal(xf->inv, n));
-        } else {
-            *point = p_obj;
-            *normal = n; /* normalize of an exact unit axis is the identity */
-        }
+        *normal = (pr->xform != 0) ? normalize3(xf_normal(xf->inv, n)) : n; /* normalize of an exact unit axis is the identity */
         break;
     }
     default: { /* volumes: volumeBox.cu:86-93, volumeSphere.cu:97-105 */
         v3 n = V(1.f, 0.f, 0.f);
-        if (pr->xform != 0) {
-            *point = xf_point(xf->m, p_obj);
-            *normal = normalize3(xf_normal(xf->inv, n));
-        } else {
-            *point = p_obj;
-            *normal = n;
-        }
+        *normal = (pr->xform != 0) ? normalize3(xf_normal(xf->inv, n)) : n;
         break;
     }
     }
@@ -545,7 +533,7 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
         } else {
             /* shaders/closehit.cu:45-121 */
             v3 hp, hn;
-            hit_attributes(sc, &h, &hp, &hn);
+            hit_attributes(sc, &h, origin, dir, &hp, &hn);
             const rtw_material* m = &sc->mats[sc->prims[h.prim].material];
             int specular = 0;
             switch (m->type) {

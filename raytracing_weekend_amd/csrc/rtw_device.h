@@ -193,13 +193,21 @@ struct BvhNode {
     uint32_t count;
 };
 
-// per-primitive shading record baked at upload: material + its (constant) texture colour
-struct Shade {
-    int32_t type;       // rtw_material_type
+// Per-primitive hit record baked at upload (64 B, fetched with one burst of four 16-byte loads once
+// the closest hit is known): material + its constant texture colour (texture/constantTexture.cu:5-10,
+// nullTexture.cu:7-12) and everything the shading normal needs, so that no primitive / transform
+// record has to be re-read per lane after traversal.
+enum { HK_CONST_NORMAL = 0, HK_SPHERE = 1, HK_MOVING_SPHERE = 2, HK_SPHERE_XFORM = 3 };
+struct HitRec {
+    int32_t mat_type;   // rtw_material_type
     int32_t bsdf_eval;
     float param;        // fuzz or eta
-    float r, g, b;      // texture/constantTexture.cu:5-10, nullTexture.cu:7-12
-    int32_t pad0, pad1;
+    int32_t kind;       // HK_*
+    float r, g, b;      // texture colour
+    float inv_r;        // spheres: 1/radius (IEEE division, done once on the host)
+    float nx, ny, nz;   // HK_CONST_NORMAL: world shading normal (rectangles, volumes); spheres: centre
+    int32_t xform;
+    float pad[4];
 };
 
 // Small-scene candidate lists, built at upload (rtw_upload_scene). 32-byte records so that one
@@ -220,7 +228,7 @@ struct BruteRec {
 struct DScene {
     const rtw_prim* __restrict__ prims;
     const rtw_xform* __restrict__ xforms;
-    const Shade* __restrict__ shade;       // indexed by primitive
+    const HitRec* __restrict__ hitrec;     // indexed by primitive
     const rtw_light* __restrict__ lights;
     const BvhNode* __restrict__ nodes;
     const int32_t* __restrict__ tree_prims;  // leaf entries -> primitive index
@@ -541,42 +549,34 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
 #undef RTW_ACCEPT
 }
 
+RTW_DEV HitRec load_hitrec(const DScene& sc, int prim) {
+    const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.hitrec + prim);
+    const u32x4 a = q[0], b = q[1], c = q[2];
+    HitRec h;
+    h.mat_type = (int)a.x; h.bsdf_eval = (int)a.y; h.param = __uint_as_float(a.z); h.kind = (int)a.w;
+    h.r = __uint_as_float(b.x); h.g = __uint_as_float(b.y); h.b = __uint_as_float(b.z); h.inv_r = __uint_as_float(b.w);
+    h.nx = __uint_as_float(c.x); h.ny = __uint_as_float(c.y); h.nz = __uint_as_float(c.z); h.xform = (int)c.w;
+    h.pad[0] = h.pad[1] = h.pad[2] = h.pad[3] = 0.f;
+    return h;
+}
+
 // Attributes of the committed hit (registers 0..7 of optixReportIntersection): world point, shading normal.
-RTW_DEV void hit_attributes(const DScene& sc, int prim, v3 o, v3 d, float t, float ray_time, float gather_time, v3& point, v3& normal) {
-    const rtw_prim pr = load_prim(sc, prim);
-    v3 oo, dd, motion;
-    object_ray(sc, pr, o, d, ray_time, oo, dd, motion);
-    v3 p_obj = vfma(dd, t, oo);
-    bool has_xf = pr.xform != 0;
-    M34 xm, xi;
-    if (has_xf) { xm = load_xf_m(sc, pr.xform); xi = load_xf_inv(sc, pr.xform); }
-    if (pr.type == RTW_PRIM_SPHERE) {
-        // sphere.cu:63-67 (Q13: world point minus object-space centre)
-        v3 pw = has_xf ? xf_point(xm.m, p_obj) : p_obj;
-        v3 n = vscale(vsub(pw, ld3(&pr.p[0])), 1.0f / pr.p[3]);
-        if (has_xf) n = xf_normal(xi.m, n);
-        point = pw; normal = n;
-    } else if (pr.type == RTW_PRIM_MOVING_SPHERE) {
-        // movingSphere.cu:83-85
-        v3 pm = vadd(p_obj, motion);
-        v3 pw = has_xf ? xf_point(xm.m, pm) : pm;
-        v3 n = vscale(vsub(pw, moving_center(pr, gather_time)), 1.0f / pr.p[3]);
-        if (has_xf) n = xf_normal(xi.m, n);
-        point = pw; normal = n;
+// The world point is the world ray evaluated at t (same real point as the reference's
+// optixTransformPointFromObjectToWorldSpace(o_obj + t*d_obj)); normals follow sphere.cu:63-67 (Q13),
+// movingSphere.cu:83-85, aarect{x,y,z}.cu:25-30, volumeBox.cu:86-93, volumeSphere.cu:97-105.
+RTW_DEV void hit_attributes(const DScene& sc, const HitRec& h, int prim, v3 o, v3 d, float t, float gather_time, v3& point, v3& normal) {
+    const v3 pw = vfma(d, t, o);
+    point = pw;
+    if (h.kind == HK_CONST_NORMAL) {
+        normal = V(h.nx, h.ny, h.nz);
+    } else if (h.kind == HK_SPHERE) {
+        normal = vscale(vsub(pw, V(h.nx, h.ny, h.nz)), h.inv_r);
     } else {
-        v3 n;
-        if (pr.type == RTW_PRIM_RECT_X) n = V(1.f, 0.f, 0.f);
-        else if (pr.type == RTW_PRIM_RECT_Y) n = V(0.f, 1.f, 0.f);
-        else if (pr.type == RTW_PRIM_RECT_Z) n = V(0.f, 0.f, 1.f);
-        else n = V(1.f, 0.f, 0.f);  // volumes: volumeBox.cu:86-93, volumeSphere.cu:97-105
-        if (pr.flip && !is_volume(pr.type)) n = vneg(n);
-        if (has_xf) {
-            point = xf_point(xm.m, p_obj);
-            normal = normalize3(xf_normal(xi.m, n));
-        } else {
-            point = p_obj;
-            normal = n;
-        }
+        const rtw_prim pr = load_prim(sc, prim);
+        v3 c = (h.kind == HK_MOVING_SPHERE) ? moving_center(pr, gather_time) : ld3(&pr.p[0]);
+        v3 n = vscale(vsub(pw, c), h.inv_r);
+        if (pr.xform != 0) { M34 xi = load_xf_inv(sc, pr.xform); n = xf_normal(xi.m, n); }
+        normal = n;
     }
 }
 

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -47,7 +48,7 @@ struct BounceArgs {
     const uint32_t* cnt_in;
     uint32_t* cnt_out;
     unsigned long long* stats;
-    uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, regroup, ablate, pad1;
+    uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, pad;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -81,14 +82,13 @@ RTW_DEV bool shade_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g
         }
         ev = EV_MISS;
     } else {
+        const HitRec hr = load_hitrec(sc, prim);
         v3 hp, hn;
-        if (A.ablate & 1u) { hp = vfma(dir, t, origin); hn = V(0.f, 1.f, 0.f); }
-        else hit_attributes(sc, prim, origin, dir, t, ray_time, gather_time, hp, hn);
-        const RTW_CONST Shade* shp = as_const(sc.shade + ((A.ablate & 2u) ? 1 : prim));
-        const int mtype = shp->type;
-        const float mparam = shp->param;
-        const v3 tex = V(shp->r, shp->g, shp->b);
-        const int bsdf_eval = shp->bsdf_eval;
+        hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
+        const int mtype = hr.mat_type;
+        const float mparam = hr.param;
+        const v3 tex = V(hr.r, hr.g, hr.b);
+        const int bsdf_eval = hr.bsdf_eval;
         bool specular = false;
         if (mtype == RTW_MAT_LAMBERTIAN) {
             // lambertianMaterial.cu:41-71, onb.cuh:20-32, sampling.cuh:49-60 (Q1)
@@ -211,7 +211,7 @@ RTW_DEV bool shade_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g
                 v3 f = vscale(att, RTW_1_PI_F);
                 float ndl = dot3(ldir, hn);
                 float bpdf = __builtin_fmaxf(0.0f, ndl * RTW_1_PI_F);
-                if (0.0f < bpdf && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f) && !(A.ablate & 4u)) {
+                if (0.0f < bpdf && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f)) {
                     const float eps = 500 * 1.0e-7f;
                     float st;
                     int sprim;
@@ -243,8 +243,6 @@ RTW_DEV bool shade_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g
 template <int KIND, bool FIRST>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceArgs A) {
     extern __shared__ uint32_t s_stack[];
-    __shared__ uint32_t s_kcnt[8][kBlock / 64];
-    __shared__ uint32_t s_rec[19][kBlock];
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u, wave = tid >> 6;
     uint32_t* my_stack = s_stack + tid;
@@ -374,61 +372,10 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceAr
         }
         float gather_time = valid_gather;
         bool live = valid;
-        if (A.regroup) {
-            // ---- wide launches: trace, then re-deal the 256 paths of this chunk to lanes by the material
-            // they hit, so that each wave shades (and light-samples, and shadow-traces) one kind of surface.
-            float t = 0.f, ray_time = 0.f;
-            int prim = -1;
-            uint32_t key = 7u;  // idle lane
-            if (valid) {
-                trace_stage<KIND>(A, A.depth, g, origin, dir, gather_time, my_stack, t, prim, ray_time);
-                key = prim < 0 ? 6u : (uint32_t)as_const(A.sc.shade + prim)->type;
-            }
-            uint32_t rank = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const unsigned long long b = __ballot(key == k);
-                if (key == k) rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-                if (lane == 0) s_kcnt[k][wave] = (uint32_t)__popcll(b);
-            }
-            __syncthreads();
-            uint32_t dest = rank, n_live = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-#pragma unroll
-                for (uint32_t w = 0; w < kBlock / 64; w++) {
-                    const uint32_t c = s_kcnt[k][w];
-                    if (k < key || (k == key && w < wave)) dest += c;
-                    if (k < 7) n_live += c;
-                }
-            }
-            s_rec[0][dest] = __float_as_uint(origin.x); s_rec[1][dest] = __float_as_uint(origin.y); s_rec[2][dest] = __float_as_uint(origin.z);
-            s_rec[3][dest] = __float_as_uint(dir.x); s_rec[4][dest] = __float_as_uint(dir.y); s_rec[5][dest] = __float_as_uint(dir.z);
-            s_rec[6][dest] = __float_as_uint(T.x); s_rec[7][dest] = __float_as_uint(T.y); s_rec[8][dest] = __float_as_uint(T.z);
-            s_rec[9][dest] = __float_as_uint(L.x); s_rec[10][dest] = __float_as_uint(L.y); s_rec[11][dest] = __float_as_uint(L.z);
-            s_rec[12][dest] = w0; s_rec[13][dest] = g.a; s_rec[14][dest] = g.b; s_rec[15][dest] = gk;
-            s_rec[16][dest] = __float_as_uint(t); s_rec[17][dest] = (uint32_t)prim; s_rec[18][dest] = __float_as_uint(ray_time);
-            __syncthreads();
-            origin = V(__uint_as_float(s_rec[0][tid]), __uint_as_float(s_rec[1][tid]), __uint_as_float(s_rec[2][tid]));
-            dir = V(__uint_as_float(s_rec[3][tid]), __uint_as_float(s_rec[4][tid]), __uint_as_float(s_rec[5][tid]));
-            T = V(__uint_as_float(s_rec[6][tid]), __uint_as_float(s_rec[7][tid]), __uint_as_float(s_rec[8][tid]));
-            L = V(__uint_as_float(s_rec[9][tid]), __uint_as_float(s_rec[10][tid]), __uint_as_float(s_rec[11][tid]));
-            w0 = s_rec[12][tid];
-            const uint32_t ra = s_rec[13][tid], rb = s_rec[14][tid];
-            gk = s_rec[15][tid];
-            t = __uint_as_float(s_rec[16][tid]); prim = (int)s_rec[17][tid]; ray_time = __uint_as_float(s_rec[18][tid]);
-            __syncthreads();  // s_rec / s_kcnt are reused by the next chunk
-            live = tid < n_live;
-            if (KIND == RTW_RNG_TEA_LCG) g.init(A.seed, 0, 0, ra, rb);
-            else g.init(A.seed, w0, rb, ra, rb);
-            gather_time = fma_((float)gk * (1.0f / 16777216.0f), A.sc.cam.time1 - A.sc.cam.time0, A.sc.cam.time0);
-            if (live) {
-                alive = shade_stage<KIND>(A, A.depth, g, origin, dir, T, L, gather_time, my_stack, n_shadow, t, prim, ray_time);
-                n_seg++;
-            }
-        } else if (valid) {
-            // ---- thin tail launches: A.n_iter consecutive bounces in registers (a launch with few paths is
-            // latency-bound, so fewer, longer launches win; lane order does not matter there).
+        if (valid) {
+            // A.n_iter consecutive bounces in registers: 1 for the wide early bounces (compaction after every
+            // segment keeps the lanes full), several for the thin tail (a launch with few paths is
+            // latency-bound, so fewer, longer launches win).
             uint32_t depth = A.depth;
             for (uint32_t it = 0; it < A.n_iter; it++) {
                 float t, ray_time;
@@ -675,7 +622,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (h.n_textures) memcpy(texs.data(), b + h.off_textures, h.n_textures * sizeof(rtw_texture));
     if (h.n_lights) memcpy(lights.data(), b + h.off_lights, h.n_lights * sizeof(rtw_light));
 
-    std::vector<Shade> shade(h.n_prims);
+    std::vector<HitRec> shade(h.n_prims);
     std::vector<int32_t> order;
     int has_motion = 0;
     for (uint32_t i = 0; i < h.n_prims; i++) {
@@ -685,8 +632,35 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         if (p.material < 0 || (uint32_t)p.material >= h.n_materials) return fail(c, RTW_ERR_BAD_SCENE, "primitive material out of range");
         if (p.type == RTW_PRIM_MOVING_SPHERE) has_motion = 1;
         const rtw_material& m = mats[p.material];
-        Shade s{};
-        s.type = m.type; s.bsdf_eval = m.bsdf_eval; s.param = m.fuzz_or_eta;
+        HitRec s{};
+        s.mat_type = m.type; s.bsdf_eval = m.bsdf_eval; s.param = m.fuzz_or_eta; s.xform = p.xform;
+        {
+            // shading-normal data, same fp32 operations and order as the device/oracle would use per hit
+            const rtw_xform& xf = xforms[p.xform];
+            auto xfn = [&](float nx, float ny, float nz, float* o3) {
+                float v[3] = {std::fmaf(xf.inv[0], nx, std::fmaf(xf.inv[4], ny, xf.inv[8] * nz)),
+                              std::fmaf(xf.inv[1], nx, std::fmaf(xf.inv[5], ny, xf.inv[9] * nz)),
+                              std::fmaf(xf.inv[2], nx, std::fmaf(xf.inv[6], ny, xf.inv[10] * nz))};
+                float dd = std::fmaf(v[2], v[2], std::fmaf(v[1], v[1], v[0] * v[0]));
+                float inv = 1.0f / std::sqrt(dd);
+                o3[0] = v[0] * inv; o3[1] = v[1] * inv; o3[2] = v[2] * inv;
+            };
+            if (p.type == RTW_PRIM_SPHERE || p.type == RTW_PRIM_MOVING_SPHERE) {
+                s.kind = p.type == RTW_PRIM_MOVING_SPHERE ? HK_MOVING_SPHERE : (p.xform != 0 ? HK_SPHERE_XFORM : HK_SPHERE);
+                s.nx = p.p[0]; s.ny = p.p[1]; s.nz = p.p[2];
+                s.inv_r = 1.0f / p.p[3];
+            } else {
+                s.kind = HK_CONST_NORMAL;
+                float n[3] = {0.f, 0.f, 0.f};
+                if (p.type == RTW_PRIM_RECT_X) n[0] = 1.f;
+                else if (p.type == RTW_PRIM_RECT_Y) n[1] = 1.f;
+                else if (p.type == RTW_PRIM_RECT_Z) n[2] = 1.f;
+                else n[0] = 1.f;  // volumes report (1,0,0)
+                if (p.flip && !rtwbvh::is_volume(p.type)) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+                if (p.xform != 0) { float w[3]; xfn(n[0], n[1], n[2], w); n[0] = w[0]; n[1] = w[1]; n[2] = w[2]; }
+                s.nx = n[0]; s.ny = n[1]; s.nz = n[2];
+            }
+        }
         if (m.texture >= 0) {
             if ((uint32_t)m.texture >= h.n_textures) return fail(c, RTW_ERR_BAD_SCENE, "material texture out of range");
             const rtw_texture& t = texs[m.texture];
@@ -744,7 +718,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     size_t o_prims = 0;
     size_t o_xf = al(o_prims + prims.size() * sizeof(rtw_prim));
     size_t o_shade = al(o_xf + xforms.size() * sizeof(rtw_xform));
-    size_t o_lights = al(o_shade + shade.size() * sizeof(Shade));
+    size_t o_lights = al(o_shade + shade.size() * sizeof(HitRec));
     size_t o_nodes = al(o_lights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
     size_t o_tree = al(o_nodes + std::max<size_t>(1, bvh.nodes.size()) * sizeof(BvhNode));
     size_t o_order = al(o_tree + std::max<size_t>(1, bvh.prim_order.size()) * sizeof(int32_t));
@@ -754,7 +728,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     std::vector<char> stage(total, 0);
     if (!prims.empty()) memcpy(stage.data() + o_prims, prims.data(), prims.size() * sizeof(rtw_prim));
     memcpy(stage.data() + o_xf, xforms.data(), xforms.size() * sizeof(rtw_xform));
-    if (!shade.empty()) memcpy(stage.data() + o_shade, shade.data(), shade.size() * sizeof(Shade));
+    if (!shade.empty()) memcpy(stage.data() + o_shade, shade.data(), shade.size() * sizeof(HitRec));
     if (!lights.empty()) memcpy(stage.data() + o_lights, lights.data(), lights.size() * sizeof(rtw_light));
     static_assert(sizeof(BvhNode) == sizeof(rtwbvh::Node), "node layout");
     if (!bvh.nodes.empty()) memcpy(stage.data() + o_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
@@ -773,7 +747,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     DScene sc{};
     sc.prims = (const rtw_prim*)(d + o_prims);
     sc.xforms = (const rtw_xform*)(d + o_xf);
-    sc.shade = (const Shade*)(d + o_shade);
+    sc.hitrec = (const HitRec*)(d + o_shade);
     sc.lights = (const rtw_light*)(d + o_lights);
     sc.nodes = (const BvhNode*)(d + o_nodes);
     sc.tree_prims = (const int32_t*)(d + o_tree);
@@ -839,10 +813,6 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         }
     }
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
-    const char* rg_env = getenv("RTW_REGROUP");
-    const bool regroup_on = (rg_env && rg_env[0] == '1');
-    const char* ab_env = getenv("RTW_ABLATE");  // timing experiments only: breaks the image on purpose
-    const uint32_t ablate = ab_env ? (uint32_t)atoi(ab_env) : 0u;
     int rc = ensure_pool(c, (size_t)regions_max * region_cap, npix, cnt_words);
     if (rc) return rc;
 
@@ -908,8 +878,6 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
                 a.cnt_out = c->cnt + (li + 1) * regions;
                 a.depth = (uint32_t)d;
                 a.n_iter = (uint32_t)sched[li].second;
-                a.regroup = (a.n_iter == 1 && regroup_on) ? 1u : 0u;
-                a.ablate = ablate;
                 if (P->rng_kind == RTW_RNG_PHILOX) {
                     if (d == 0) launch_bounce<RTW_RNG_PHILOX, true>(a, grid, lds, s);
                     else launch_bounce<RTW_RNG_PHILOX, false>(a, grid, lds, s);
