@@ -1,0 +1,70 @@
+"""world_size-2 gloo rehearsal of the N>1 path: row-tile partition, per-rank tile render, one gather,
+assembly on rank 0. On the CPU the per-rank renderer is the oracle (test-only); on the GPU bench.py
+runs the same plumbing with rtw_render_device and the nccl (RCCL) backend."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_path, h, w):
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle
+    from raytracing_weekend_amd import abi
+    from raytracing_weekend_amd.dist import gather_tiles, partition_rows
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = partition_rows(h, world)
+    max_rows = max(rows[g + 1] - rows[g] for g in range(world))
+    blob = abi.build_scene(0, w, h)
+    p = abi.make_params(w, h, 3, 5, row0=rows[rank], row1=rows[rank + 1])
+    img, _ = oracle.render(blob, p, threads=2)
+    tile = torch.zeros((max_rows, w, 4), dtype=torch.float32)
+    tile[: img.shape[0]] = torch.from_numpy(img)
+    full = gather_tiles(tile, rows, rank, world)
+    dist.barrier()
+    if rank == 0:
+        np.save(out_path, full.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,h", [(2, 37), (3, 20)])
+def test_row_tile_gather_matches_single_process(tmp_path, world, h):
+    w = 48
+    for p in (ROOT, os.path.join(ROOT, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import oracle
+    from raytracing_weekend_amd import abi
+    out = str(tmp_path / "full.npy")
+    mp.spawn(_worker, args=(world, _free_port(), out, h, w), nprocs=world, join=True)
+    got = np.load(out)
+    want, _ = oracle.render(abi.build_scene(0, w, h), abi.make_params(w, h, 3, 5), threads=2)
+    assert got.shape == (h, w, 4)
+    assert np.array_equal(got, want)
+
+
+def test_partition_rows_covers_the_image():
+    from raytracing_weekend_amd.dist import partition_rows
+    for h in (1, 7, 1080, 4320):
+        for n in (1, 2, 3, 4, 8):
+            r = partition_rows(h, n)
+            assert r[0] == 0 and r[-1] == h and all(0 <= r[i + 1] - r[i] <= -(-h // n) for i in range(n))
