@@ -182,7 +182,20 @@ RTW_DEV bool shade_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g
                 il = (int)__builtin_floorf(g.next1() * (float)nl);
                 il = il < 0 ? 0 : (il > nl - 1 ? nl - 1 : il);
             }
-            const RTW_CONST rtw_light* lt = as_const(sc.lights + il);
+            // one light (the usual case): the record index is wave-uniform, so it is read through the scalar cache
+            v3 lnrm, lemi;
+            float larea;
+            if (nl > 1) {
+                const RTW_CONST rtw_light* lt = as_const(sc.lights + il);
+                lnrm = V(lt->normal[0], lt->normal[1], lt->normal[2]);
+                lemi = V(lt->emission[0], lt->emission[1], lt->emission[2]);
+                larea = lt->area;
+            } else {
+                const RTW_CONST rtw_light* lt = as_const(sc.lights);
+                lnrm = V(lt->normal[0], lt->normal[1], lt->normal[2]);
+                lemi = V(lt->emission[0], lt->emission[1], lt->emission[2]);
+                larea = lt->area;
+            }
             int gen = sc.pdf.gen;  // mixturePdf.cu:25-38: always child p1 (Q4)
             if (gen == RTW_PDF_MIXTURE || gen == RTW_PDF_MIXTURE_BIAS) gen = sc.pdf.p1_gen;
             float lpdf = 0.0f, ldist = 0.0f;
@@ -199,10 +212,10 @@ RTW_DEV bool shade_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g
                 ldist = length3(ldir);
                 if (ldist > 1.0e-6f) {
                     ldir = vscale(ldir, 1.0f / ldist);
-                    float costa = dot3(vneg(ldir), V(lt->normal[0], lt->normal[1], lt->normal[2]));
+                    float costa = dot3(vneg(ldir), lnrm);
                     if (costa > 1.0e-6f) {
-                        lem = vscale(V(lt->emission[0], lt->emission[1], lt->emission[2]), (float)nl);
-                        lpdf = (ldist * ldist) / (lt->area * costa);
+                        lem = vscale(lemi, (float)nl);
+                        lpdf = (ldist * ldist) / (larea * costa);
                     }
                 }
             }
@@ -252,6 +265,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceAr
     // (<= kMaxRegions) counters into an LDS prefix array once, then strides over the virtual chunk
     // ids: no empty iterations, perfect balance, and a launch with nothing alive costs one scan.
     __shared__ uint32_t s_pref[kMaxRegions + 1];
+    __shared__ uint32_t s_raw[kMaxRegions];
     __shared__ uint32_t s_part[kBlock];
     uint32_t total_chunks;
     const uint32_t chunks_per_region = A.region_cap / kBlock;
@@ -264,7 +278,9 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceAr
 #pragma unroll
         for (uint32_t j = 0; j < kPer; j++) {
             const uint32_t r = tid * kPer + j;
-            const uint32_t c = r < A.n_regions ? (A.cnt_in[r] + kBlock - 1) / kBlock : 0u;
+            const uint32_t raw = r < A.n_regions ? A.cnt_in[r] : 0u;
+            s_raw[r] = raw;
+            const uint32_t c = (raw + kBlock - 1) / kBlock;
             loc[j] = sum;
             sum += c;
         }
@@ -299,7 +315,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceAr
             }
             region = lo;
             chunk = vc - s_pref[lo];
-            n_in = A.cnt_in[region];
+            n_in = s_raw[region];
         }
         const uint32_t idx = chunk * kBlock + tid;
         const bool valid = idx < n_in;
@@ -669,7 +685,9 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         }
         shade[i] = s;
     }
-    const bool use_bvh = (int)h.n_prims > kBruteMaxPrims;
+    int brute_max = kBruteMaxPrims;
+    if (const char* e = getenv("RTW_BRUTE_MAX")) brute_max = atoi(e);  // experiments: 0 forces the BVH path
+    const bool use_bvh = (int)h.n_prims > brute_max;
     // order[]: volumes (index order), then -- small scenes only -- the moving spheres, which keep the generic test
     for (uint32_t i = 0; i < h.n_prims; i++) if (rtwbvh::is_volume(prims[i].type)) order.push_back((int32_t)i);
     const int n_vol = (int)order.size();
