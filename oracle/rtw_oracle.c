@@ -685,7 +685,8 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
                 }
             }
         }
-        L = V(fmaf(radiance.x, T.x, L.x), fmaf(radiance.y, T.y, L.y), fmaf(radiance.z, T.z, L.z));
+        L = vadd(L, vmul(radiance, T)); /* raygen.cu:60 — product, then sum: the GPU may hold the product of a light sample
+                                         * until its shadow probe is back and add it then, with the same two roundings */
         if (ev != EV_HIT) break;
         origin = so; dir = sd;
         T = vmul(T, att);

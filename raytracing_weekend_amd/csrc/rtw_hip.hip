@@ -1,19 +1,19 @@
 // rtw_hip.hip — wavefront Monte-Carlo path tracer for MI355X (gfx950) behind the C ABI of include/rtw.h.
 //
 // What the reference does in ONE OptiX megakernel launch (Director.cpp:982-984: raygen -> traverse ->
-// closest-hit/miss -> callables, one thread per pixel, one sample) is done here as a wavefront loop:
+// closest-hit/miss -> callables, one thread per pixel, one sample) is done here as a wavefront loop over
+// batches of S samples per pixel (P = pixels*S paths in flight, sized for HBM, not for cache):
 //
-//   per batch of S samples per pixel (P = pixels*S paths in flight, sized for HBM not for cache):
-//     k_bounce<FIRST>   generate primary rays in registers, trace+shade segment 0
-//     k_bounce  x (max_depth-1)   one launch per bounce: load 64 B path state (4 coalesced 16 B planes),
-//                        closest hit, material scatter, light sample + shadow probe, Russian roulette,
-//                        then wave64 ballot/popcount compaction of the survivors into the other
-//                        ping-pong buffer; finished paths drop their radiance into lbuf[path]
-//     k_resolve         sums the S sample slots of each pixel in sample order (deterministic)
-//   k_finish            mean radiance -> float4 framebuffer tile
+//   k_first                     primary rays + their closest hit
+//   repeat for the wide bounces (scenes without volumes):
+//     k_shade                   material scatter, light sample (shadow probe queued), roulette, compaction
+//     k_trace                   radiance ray + queued shadow probe of every surviving path (high occupancy)
+//   k_bounce x few              thin tail: several fused bounces per launch, in registers
+//   k_resolve                   sums the S sample slots of each pixel in sample order (deterministic)
+//   k_finish (once)             mean radiance -> float4 framebuffer tile
 //
 // No OptiX, no CUDA shims, no Triton, no MFMA (divergent scalar fp32). Results do not depend on
-// scheduling: every path owns a counter-based RNG stream and its own lbuf slot.
+// scheduling: every path owns a counter-based RNG stream and its own radiance slot.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -27,458 +27,12 @@
 #include "../../include/rtw.h"
 #include "rtw_bvh.h"
 #include "rtw_device.h"
+#include "rtw_kernels.h"
 
 using namespace rtwdev;
+using namespace rtwk;
 
-namespace {
-
-#ifndef RTW_MIN_WAVES
-#define RTW_MIN_WAVES 1  // __launch_bounds__ second argument: minimum waves per SIMD the register allocator must allow
-#endif
-constexpr int kBlock = 256;                 // 4 wave64 per workgroup
-constexpr uint32_t kMinRegionCap = 64 * kBlock;  // a region holds at least 64 chunks of 256 paths
-constexpr uint32_t kMaxRegions = 2048;           // region counters scanned in LDS by every workgroup
-constexpr int kBruteMaxPrims = 24;          // at or below: scalar-cache brute force; above: BVH
-
-struct BounceArgs {
-    DScene sc;
-    const float4* in0; const float4* in1; const float4* in2; const uint4* in3;
-    float4* out0; float4* out1; float4* out2; uint4* out3;
-    float4* lbuf;
-    const uint32_t* cnt_in;
-    uint32_t* cnt_out;
-    unsigned long long* stats;
-    uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, pad;
-};
-
-// ---------------------------------------------------------------------------------------------
-// One path segment: optixTraverse + closest-hit / miss + the tail of rayColor's loop body
-// (raygen/raygen.cu:36-84, shaders/closehit.cu:45-121, miss/miss.cu:8-30).
-// Returns true when the path continues into the next bounce.
-// Stage 1 of a segment: the radiance ray's closest hit (optixTraverse, raygen.cu:41-54).
-template <int KIND>
-RTW_DEV void trace_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, const v3 origin, const v3 dir, float gather_time,
-                         uint32_t* stack, float& t, int& prim, float& ray_time) {
-    const DScene& sc = A.sc;
-    ray_time = 0.0f;
-    if (KIND == RTW_RNG_TEA_LCG || sc.has_motion) ray_time = g.ray_time(depth);  // raygen.cu:48
-    traverse<Rng<KIND>, false, false>(sc, origin, dir, 1e-6f, 1.e27f, ray_time, gather_time, g, stack, A.stack_stride, t, prim);
-}
-
-// Stage 2: closest-hit / miss programs + the tail of rayColor's loop body.
-template <int KIND>
-RTW_DEV bool shade_stage(const BounceArgs& A, const uint32_t depth, Rng<KIND>& g, v3& origin, v3& dir, v3& T, v3& L, float gather_time,
-                         uint32_t* stack, uint32_t& n_shadow, const float t, const int prim, const float ray_time) {
-    const DScene& sc = A.sc;
-    v3 radiance = V(0.f, 0.f, 0.f);
-    int ev;
-    v3 att = V(0.f, 0.f, 0.f), so = origin, sd = dir;
-    if (prim < 0) {
-        if (sc.sky_light) {  // miss.cu:8-21
-            v3 u = normalize3(dir);
-            float tt = 0.5f * (u.y + 1.0f);
-            float w = 1.0f - tt;
-            radiance = V(fma_(tt, 0.5f, w), fma_(tt, 0.7f, w), fma_(tt, 1.0f, w));
-        }
-        ev = EV_MISS;
-    } else {
-        const HitRec hr = load_hitrec(sc, prim);
-        v3 hp, hn;
-        hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
-        const int mtype = hr.mat_type;
-        const float mparam = hr.param;
-        const v3 tex = V(hr.r, hr.g, hr.b);
-        const int bsdf_eval = hr.bsdf_eval;
-        bool specular = false;
-        if (mtype == RTW_MAT_LAMBERTIAN) {
-            // lambertianMaterial.cu:41-71, onb.cuh:20-32, sampling.cuh:49-60 (Q1)
-            v3 w = normalize3(hn);
-            v3 a = (w.x > 0.9f || w.x < -0.9f) ? V(0.f, 1.f, 0.f) : V(1.f, 0.f, 0.f);
-            v3 v = normalize3(cross3(w, a));
-            v3 u = cross3(w, v);
-            float r1 = g.next1();
-            float r2 = g.next1();
-            float sn, cs;
-            sincos2pi(r1, sn, cs);
-            float sq = __builtin_sqrtf(r2);
-            float lx = (cs * 2.0f) * sq;
-            float ly = (sn * 2.0f) * sq;
-            float lz = __builtin_sqrtf(1.0f - r2);
-            float pdf = lz * RTW_1_PI_F;
-            v3 sdir = V(fma_(lz, w.x, fma_(ly, v.x, lx * u.x)),
-                        fma_(lz, w.y, fma_(ly, v.y, lx * u.y)),
-                        fma_(lz, w.z, fma_(ly, v.z, lx * u.z)));
-            sdir = normalize3(sdir);
-            so = hp; sd = sdir;
-            float cosine = dot3(hn, sdir);
-            ev = EV_HIT;
-            if (cosine <= 0.0f || pdf <= 0.0f) ev = EV_CANCEL;
-            else att = tex;
-        } else if (mtype == RTW_MAT_DIFFUSE_LIGHT) {
-            // diffuseLight.cu:48-69
-            if (dot3(hn, dir) < 0.0f) radiance = tex;
-            ev = EV_CANCEL;
-        } else if (mtype == RTW_MAT_METAL) {
-            // metalMaterial.cu:32-64 (Q5)
-            specular = true;
-            v3 refl = reflect3(dir, hn);
-            v3 ball = random_in_unit_sphere(g);
-            v3 sdir = normalize3(vfma(ball, mparam, refl));
-            so = hp; sd = sdir;
-            att = tex;
-            ev = (dot3(sdir, hn) <= 0.0f) ? EV_CANCEL : EV_HIT;
-        } else if (mtype == RTW_MAT_DIELECTRIC) {
-            // dielectricMaterial.cu:37-114
-            specular = true;
-            v3 unit = normalize3(dir);
-            v3 ln;
-            float eta_i, eta_t;
-            if (dot3(dir, hn) < 0.0f) { ln = hn; eta_i = 1.0f; eta_t = mparam; }
-            else { ln = vneg(hn); eta_i = mparam; eta_t = 1.0f; }
-            float cos_i = __builtin_fminf(dot3(vneg(unit), ln), 1.0f);
-            float sin_i = __builtin_sqrtf(fma_(-cos_i, cos_i, 1.0f));
-            float ratio = eta_i / eta_t;
-            v3 sdir;
-            if (ratio * sin_i > 1.0f) {
-                sdir = reflect3(unit, ln);
-            } else {
-                float r0 = (eta_i - eta_t) / (eta_i + eta_t);
-                r0 = r0 * r0;
-                float om = 1.0f - cos_i;
-                float om2 = om * om;
-                float p5 = (om2 * om2) * om;
-                float refl_prob = fma_(1.0f - r0, p5, r0);
-                if (g.next1() < refl_prob) {
-                    sdir = reflect3(unit, ln);
-                } else {
-                    float sin_t = __builtin_fminf(ratio * sin_i, 1.0f);
-                    float cos_t = __builtin_sqrtf(fma_(-sin_t, sin_t, 1.0f));
-                    v3 a = vscale(vfma(ln, cos_i, unit), ratio);
-                    sdir = vfma(ln, -cos_t, a);
-                }
-            }
-            so = hp; sd = sdir;
-            att = V(1.f, 1.f, 1.f);
-            ev = EV_HIT;
-        } else if (mtype == RTW_MAT_ISOTROPIC) {
-            // isotropicMaterial.cu:30-51 (Q14)
-            specular = true;
-            sd = random_in_unit_sphere(g);
-            so = hp;
-            att = tex;
-            ev = EV_HIT;
-        } else {
-            // normalMaterial.cu:21-31
-            specular = true;
-            att = vfma(hn, 0.5f, V(0.5f, 0.5f, 0.5f));
-            ev = EV_FINISH;
-        }
-
-        // next-event estimation, closehit.cu:70-118
-        const int nl = sc.n_lights;
-        if (ev == EV_HIT && !specular && nl > 0) {
-            int il = 0;
-            if (nl > 1) {
-                il = (int)__builtin_floorf(g.next1() * (float)nl);
-                il = il < 0 ? 0 : (il > nl - 1 ? nl - 1 : il);
-            }
-            // one light (the usual case): the record index is wave-uniform, so it is read through the scalar cache
-            v3 lnrm, lemi;
-            float larea;
-            if (nl > 1) {
-                const RTW_CONST rtw_light* lt = as_const(sc.lights + il);
-                lnrm = V(lt->normal[0], lt->normal[1], lt->normal[2]);
-                lemi = V(lt->emission[0], lt->emission[1], lt->emission[2]);
-                larea = lt->area;
-            } else {
-                const RTW_CONST rtw_light* lt = as_const(sc.lights);
-                lnrm = V(lt->normal[0], lt->normal[1], lt->normal[2]);
-                lemi = V(lt->emission[0], lt->emission[1], lt->emission[2]);
-                larea = lt->area;
-            }
-            int gen = sc.pdf.gen;  // mixturePdf.cu:25-38: always child p1 (Q4)
-            if (gen == RTW_PDF_MIXTURE || gen == RTW_PDF_MIXTURE_BIAS) gen = sc.pdf.p1_gen;
-            float lpdf = 0.0f, ldist = 0.0f;
-            v3 ldir = V(0.f, 0.f, 0.f), lem = V(0.f, 0.f, 0.f);
-            if (gen == RTW_PDF_RECT_X || gen == RTW_PDF_RECT_Y || gen == RTW_PDF_RECT_Z) {
-                // rectPdf.cu:124-193
-                float ra = g.next1();
-                float rb = g.next1();
-                float pa = fma_(ra, sc.pdf.rect[1] - sc.pdf.rect[0], sc.pdf.rect[0]);
-                float pb = fma_(rb, sc.pdf.rect[3] - sc.pdf.rect[2], sc.pdf.rect[2]);
-                float k = sc.pdf.rect[4];
-                v3 rp = (gen == RTW_PDF_RECT_X) ? V(k, pa, pb) : (gen == RTW_PDF_RECT_Y) ? V(pa, k, pb) : V(pa, pb, k);
-                ldir = vsub(rp, so);
-                ldist = length3(ldir);
-                if (ldist > 1.0e-6f) {
-                    ldir = vscale(ldir, 1.0f / ldist);
-                    float costa = dot3(vneg(ldir), lnrm);
-                    if (costa > 1.0e-6f) {
-                        lem = vscale(lemi, (float)nl);
-                        lpdf = (ldist * ldist) / (larea * costa);
-                    }
-                }
-            }
-            if (lpdf > 0.0f && bsdf_eval == 0) {
-                // lambertianMaterial.cu:74-81
-                v3 f = vscale(att, RTW_1_PI_F);
-                float ndl = dot3(ldir, hn);
-                float bpdf = __builtin_fmaxf(0.0f, ndl * RTW_1_PI_F);
-                if (0.0f < bpdf && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f)) {
-                    const float eps = 500 * 1.0e-7f;
-                    float st;
-                    int sprim;
-                    traverse<Rng<KIND>, true, false>(sc, so, ldir, eps, ldist - eps, 0.0f, gather_time, g, stack, A.stack_stride, st, sprim);
-                    n_shadow++;
-                    if (sprim < 0) {
-                        float a2 = lpdf * lpdf;
-                        float weight = a2 / fma_(bpdf, bpdf, a2);  // raydata.cuh:167-171
-                        float k = (weight * ndl) / lpdf;
-                        radiance = vadd(radiance, vscale(vmul(f, lem), k));
-                    }
-                }
-            }
-        }
-    }
-    L = V(fma_(radiance.x, T.x, L.x), fma_(radiance.y, T.y, L.y), fma_(radiance.z, T.z, L.z));  // raygen.cu:60
-    if (ev != EV_HIT) return false;
-    origin = so; dir = sd;
-    T = vmul(T, att);
-    if (2u <= depth) {  // raygen.cu:74-82
-        float p = __builtin_fmaxf(__builtin_fmaxf(T.x, T.y), T.z);
-        if (p < g.next1()) return false;
-        T = vscale(T, 1.0f / p);
-    }
-    return depth + 1u < A.max_depth;
-}
-
-// ---------------------------------------------------------------------------------------------
-template <int KIND, bool FIRST>
-__global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const BounceArgs A) {
-    extern __shared__ uint32_t s_stack[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    uint32_t* my_stack = s_stack + tid;
-    uint32_t n_seg = 0, n_shadow = 0;
-
-    // Work list. Region r holds cnt_in[r] live paths = ceil(cnt/256) chunks. Every workgroup scans the
-    // (<= kMaxRegions) counters into an LDS prefix array once, then strides over the virtual chunk
-    // ids: no empty iterations, perfect balance, and a launch with nothing alive costs one scan.
-    __shared__ uint32_t s_pref[kMaxRegions + 1];
-    __shared__ uint32_t s_raw[kMaxRegions];
-    __shared__ uint32_t s_part[kBlock];
-    uint32_t total_chunks;
-    const uint32_t chunks_per_region = A.region_cap / kBlock;
-    if (FIRST) {
-        total_chunks = (A.n_paths + kBlock - 1) / kBlock;
-    } else {
-        constexpr uint32_t kPer = kMaxRegions / kBlock;
-        uint32_t loc[kPer];
-        uint32_t sum = 0;
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) {
-            const uint32_t r = tid * kPer + j;
-            const uint32_t raw = r < A.n_regions ? A.cnt_in[r] : 0u;
-            s_raw[r] = raw;
-            const uint32_t c = (raw + kBlock - 1) / kBlock;
-            loc[j] = sum;
-            sum += c;
-        }
-        s_part[tid] = sum;
-        __syncthreads();
-        for (uint32_t off = 1; off < kBlock; off <<= 1) {
-            uint32_t v = tid >= off ? s_part[tid - off] : 0u;
-            __syncthreads();
-            s_part[tid] += v;
-            __syncthreads();
-        }
-        const uint32_t excl = s_part[tid] - sum;
-#pragma unroll
-        for (uint32_t j = 0; j < kPer; j++) s_pref[tid * kPer + j] = excl + loc[j];
-        if (tid == kBlock - 1) s_pref[kMaxRegions] = s_part[tid];
-        __syncthreads();
-        total_chunks = s_pref[kMaxRegions];
-    }
-    for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
-        uint32_t region, chunk, n_in;
-        if (FIRST) {
-            region = vc / chunks_per_region;
-            chunk = vc - region * chunks_per_region;
-            const uint32_t lo = region * A.region_cap;
-            n_in = min(A.region_cap, A.n_paths - lo);
-        } else {
-            // largest r with s_pref[r] <= vc
-            uint32_t lo = 0, hi = A.n_regions;
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (s_pref[mid] <= vc) lo = mid; else hi = mid;
-            }
-            region = lo;
-            chunk = vc - s_pref[lo];
-            n_in = s_raw[region];
-        }
-        const uint32_t idx = chunk * kBlock + tid;
-        const bool valid = idx < n_in;
-        const size_t slot_in = (size_t)region * A.region_cap + idx;
-
-        bool alive = false;
-        v3 origin = V(0, 0, 0), dir = V(0, 0, 0), T = V(1, 1, 1), L = V(0, 0, 0);
-        uint32_t w0 = 0, gk = 0;
-        float valid_gather = 0.f;
-        Rng<KIND> g;
-        g.init(A.seed, 0, 0, 0, 0);
-        if (valid) {
-            float gather_time;
-            if (FIRST) {
-                // __raygen__Program (raygen.cu:123-147) + perspectiveCamera (camera.cu:11-19) + color() (raygen.cu:89-95)
-                const uint32_t path_id = (uint32_t)slot_in;
-                const uint32_t slot = path_id / A.npix;
-                const uint32_t pl = path_id - slot * A.npix;
-                const uint32_t yl = pl / A.width;
-                const uint32_t x = pl - yl * A.width;
-                const uint32_t y = A.row0 + yl;
-                const uint32_t pixel = A.width * y + x;
-                const uint32_t sample = A.sample0 + slot;
-                float r0, r1, r2, r3, r4;
-                if (KIND == RTW_RNG_TEA_LCG) {
-                    uint32_t s = tea<64>(pixel, sample);  // raygen.cu:129
-                    r0 = lcg_rnd(s); r1 = lcg_rnd(s); r2 = lcg_rnd(s); r3 = lcg_rnd(s);
-                    g.init(A.seed, pixel, sample, s, s);  // prd.seed = seed; rayColor's local copy (Q7)
-                    r4 = lcg_rnd(s);
-                    w0 = path_id;
-                } else {
-                    uint32_t o[4];
-                    philox4x32_10(pixel, sample, 0u, 0u, A.seed, 0u, o);
-                    r0 = u24(o[0]); r1 = u24(o[1]); r2 = u24(o[2]); r3 = u24(o[3]);
-                    philox4x32_10(pixel, sample, 1u, 0u, A.seed, 0u, o);
-                    r4 = u24(o[0]);
-                    g.init(A.seed, pixel, sample, 0u, sample);
-                    w0 = pixel;
-                }
-                const rtw_camera& cam = A.sc.cam;
-                float s = ((float)x + r0) / (float)A.width;
-                float t = ((float)y + r1) / (float)A.height;
-                origin = ld3(cam.origin);
-                if (cam.lens_radius != 0.0f) {  // sampling.cuh:15-22; the two draws are consumed either way
-                    float sn, cs;
-                    sincos2pi(r2, sn, cs);
-                    float sq = __builtin_sqrtf(r3);
-                    float rx = cam.lens_radius * (sn * sq);
-                    float ry = cam.lens_radius * (cs * sq);
-                    origin = vadd(origin, vfma(ld3(cam.v), ry, vscale(ld3(cam.u), rx)));
-                }
-                dir = vfma(ld3(cam.horizontal), s, ld3(cam.lower_left));
-                dir = vfma(ld3(cam.vertical), t, dir);
-                dir = vsub(dir, origin);
-                gk = (uint32_t)(r4 * 16777216.0f);
-                gather_time = fma_(r4, cam.time1 - cam.time0, cam.time0);
-            } else {
-                float4 p0 = A.in0[slot_in], p1 = A.in1[slot_in], p2 = A.in2[slot_in];
-                uint4 p3 = A.in3[slot_in];
-                origin = V(p0.x, p0.y, p0.z);
-                dir = V(p0.w, p1.x, p1.y);
-                T = V(p1.z, p1.w, p2.x);
-                L = V(p2.y, p2.z, p2.w);
-                w0 = p3.x; gk = p3.w;
-                if (KIND == RTW_RNG_TEA_LCG) g.init(A.seed, 0, 0, p3.y, p3.z);
-                else g.init(A.seed, w0, p3.z, p3.y, p3.z);  // word 2 carries the sample index
-                gather_time = fma_((float)gk * (1.0f / 16777216.0f), A.sc.cam.time1 - A.sc.cam.time0, A.sc.cam.time0);
-            }
-            valid_gather = gather_time;
-        }
-        float gather_time = valid_gather;
-        bool live = valid;
-        if (valid) {
-            // A.n_iter consecutive bounces in registers: 1 for the wide early bounces (compaction after every
-            // segment keeps the lanes full), several for the thin tail (a launch with few paths is
-            // latency-bound, so fewer, longer launches win).
-            uint32_t depth = A.depth;
-            for (uint32_t it = 0; it < A.n_iter; it++) {
-                float t, ray_time;
-                int prim;
-                trace_stage<KIND>(A, depth, g, origin, dir, gather_time, my_stack, t, prim, ray_time);
-                alive = shade_stage<KIND>(A, depth, g, origin, dir, T, L, gather_time, my_stack, n_shadow, t, prim, ray_time);
-                n_seg++;
-                depth++;
-                if (!alive) break;
-            }
-        }
-        if (live && !alive) {
-            uint32_t path_id = w0;
-            if (KIND == RTW_RNG_PHILOX) path_id = (g.b - A.sample0) * A.npix + (w0 - A.row0 * A.width);
-            // removeNaNs, raygen.cu:17-24
-            float lx = (L.x == L.x) ? L.x : 0.f, ly = (L.y == L.y) ? L.y : 0.f, lz = (L.z == L.z) ? L.z : 0.f;
-            A.lbuf[path_id] = make_float4(lx, ly, lz, 0.f);
-        }
-        // wave64 ballot + popcount prefix; one atomic per wave reserves its slice of the region's output
-        const unsigned long long ballot = __ballot(alive);
-        if (ballot) {
-            const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(&A.cnt_out[region], (uint32_t)__popcll(ballot));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (alive) {
-                const size_t so = (size_t)region * A.region_cap + base + before;
-                A.out0[so] = make_float4(origin.x, origin.y, origin.z, dir.x);
-                A.out1[so] = make_float4(dir.y, dir.z, T.x, T.y);
-                A.out2[so] = make_float4(T.z, L.x, L.y, L.z);
-                A.out3[so] = make_uint4(w0, g.a, g.b, gk);
-            }
-        }
-    }
-    // statistics: wave reduction, one atomic pair per wave
-    for (int off = 32; off > 0; off >>= 1) {
-        n_seg += __shfl_down(n_seg, off);
-        n_shadow += __shfl_down(n_shadow, off);
-    }
-    if (lane == 0 && (n_seg | n_shadow)) {
-        atomicAdd(&A.stats[0], (unsigned long long)n_seg);
-        atomicAdd(&A.stats[1], (unsigned long long)n_shadow);
-    }
-}
-
-// sums the S sample slots of every pixel in ascending sample order (fixed order => reproducible bits)
-__global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ lbuf, float4* __restrict__ accum, uint32_t npix, uint32_t nslots) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        float4 a = accum[i];
-        for (uint32_t s = 0; s < nslots; s++) {
-            float4 l = lbuf[(size_t)s * npix + i];
-            a.x += l.x; a.y += l.y; a.z += l.z;
-        }
-        accum[i] = a;
-    }
-}
-
-__global__ void __launch_bounds__(kBlock) k_finish(const float4* __restrict__ accum, float4* __restrict__ out, uint32_t npix, float spp) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        float4 a = accum[i];
-        out[i] = make_float4(a.x / spp, a.y / spp, a.z / spp, 1.0f);
-    }
-}
-
-struct NoRng {
-    uint32_t a, b;
-    RTW_DEV float next1() { return 0.5f; }
-    RTW_DEV float randf1() { return 0.5f; }
-};
-
-__global__ void __launch_bounds__(kBlock) k_debug_intersect(const DScene sc, const float* __restrict__ rays, const float* __restrict__ ray_time,
-                                                           const float* __restrict__ gather_time, int n, float* __restrict__ out_t,
-                                                           int32_t* __restrict__ out_prim, uint32_t stack_stride) {
-    extern __shared__ uint32_t s_stack[];
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float* r = rays + 8 * (size_t)i;
-    NoRng g;
-    float t;
-    int prim;
-    traverse<NoRng, false, true>(sc, V(r[0], r[1], r[2]), V(r[3], r[4], r[5]), r[6], r[7], ray_time ? ray_time[i] : 0.f,
-                                 gather_time ? gather_time[i] : 0.f, g, s_stack + threadIdx.x, stack_stride, t, prim);
-    out_t[i] = t;
-    out_prim[i] = prim;
-}
-
-}  // namespace
+constexpr int kBruteMaxPrims = 24;  // at or below: scalar-cache brute lists; above: BVH with the LDS stack
 
 // =============================================================================================
 // host side of the library
@@ -493,8 +47,8 @@ struct rtw_ctx {
     int stack_depth = 0;
     // render pool
     size_t pool_paths = 0;
-    float4* planes[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
-    uint4* plane3[2] = {nullptr, nullptr};
+    PathBuf buf[2] = {};
+    uint2* hit = nullptr;
     float4* lbuf = nullptr;
     float4* accum = nullptr;
     size_t accum_pix = 0;
@@ -523,10 +77,12 @@ int fail(rtw_ctx* c, int code, const std::string& msg) {
 
 void free_pool(rtw_ctx* c) {
     for (int b = 0; b < 2; b++) {
-        for (int k = 0; k < 3; k++) { if (c->planes[b][k]) (void)hipFree(c->planes[b][k]); c->planes[b][k] = nullptr; }
-        if (c->plane3[b]) (void)hipFree(c->plane3[b]);
-        c->plane3[b] = nullptr;
+        void* pl[6] = {c->buf[b].p0, c->buf[b].p1, c->buf[b].p2, c->buf[b].p3, c->buf[b].p4, c->buf[b].p5};
+        for (void* q : pl) if (q) (void)hipFree(q);
+        c->buf[b] = PathBuf{};
     }
+    if (c->hit) (void)hipFree(c->hit);
+    c->hit = nullptr;
     if (c->lbuf) (void)hipFree(c->lbuf);
     c->lbuf = nullptr;
     c->pool_paths = 0;
@@ -536,9 +92,14 @@ int ensure_pool(rtw_ctx* c, size_t paths, size_t npix, size_t cnt_words) {
     if (paths > c->pool_paths) {
         free_pool(c);
         for (int b = 0; b < 2; b++) {
-            for (int k = 0; k < 3; k++) HIP_TRY(c, hipMalloc(&c->planes[b][k], paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&c->plane3[b], paths * sizeof(uint4)));
+            HIP_TRY(c, hipMalloc(&c->buf[b].p0, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&c->buf[b].p1, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&c->buf[b].p2, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&c->buf[b].p3, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&c->buf[b].p4, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&c->buf[b].p5, paths * sizeof(uint4)));
         }
+        HIP_TRY(c, hipMalloc(&c->hit, paths * sizeof(uint2)));
         HIP_TRY(c, hipMalloc(&c->lbuf, paths * sizeof(float4)));
         c->pool_paths = paths;
     }
@@ -567,9 +128,26 @@ size_t pool_target_paths() {
     return (size_t)1 << 26;  // 67 M paths in flight: 9 GiB of ping-pong state + radiance slots (HBM-sized on purpose: long batches amortise the thin tail launches)
 }
 
-template <int KIND, bool FIRST>
-void launch_bounce(const BounceArgs& a, int grid, size_t lds, hipStream_t s) {
-    hipLaunchKernelGGL((k_bounce<KIND, FIRST>), dim3(grid), dim3(kBlock), lds, s, a);
+enum { LK_FIRST, LK_SHADE, LK_TRACE, LK_BOUNCE };
+void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s) {
+    const bool lcg = rng_kind == RTW_RNG_TEA_LCG;
+    switch (which) {
+    case LK_FIRST:
+        if (lcg) hipLaunchKernelGGL((k_first<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_first<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), lds, s, a);
+        break;
+    case LK_SHADE:
+        if (lcg) hipLaunchKernelGGL((k_shade<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_shade<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), 0, s, a);
+        break;
+    case LK_TRACE:
+        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), lds, s, a);
+        break;
+    default:
+        if (lcg) hipLaunchKernelGGL((k_bounce<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_bounce<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), lds, s, a);
+        break;
+    }
 }
 
 }  // namespace
@@ -814,26 +392,40 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     // region capacity: a multiple of 256 paths, at least 16384, large enough that <= kMaxRegions regions cover the pool
     size_t region_cap = std::max<size_t>(kMinRegionCap, (((paths_max + kMaxRegions - 1) / kMaxRegions) + kBlock - 1) / kBlock * kBlock);
     const uint32_t regions_max = (uint32_t)((paths_max + region_cap - 1) / region_cap);
-    // launch schedule: (first depth, bounces in registers). Early bounces one per launch; the tail in growing groups.
-    std::vector<std::pair<int, int>> sched;
+    bool split_first = false;
+    // Launch schedule of one batch. Wide bounces: one k_shade + one k_trace per bounce (split pipeline; scenes
+    // whose intersection programs draw random numbers keep trace and shade fused in k_bounce instead).
+    // Thin tail: k_bounce with several bounces in registers, in growing groups.
+    struct Step { int kind, depth, n_iter; };
+    std::vector<Step> sched;
     {
         const char* e = getenv("RTW_TAIL_START");
         const int tail_start = (e && *e) ? std::max(1, atoi(e)) : 4;
+        const bool split = c->sc.n_vol == 0 && !(getenv("RTW_FUSED") && getenv("RTW_FUSED")[0] == '1');
         int d = 0, grp = 2, rep = 0;
         while (d < P->max_depth) {
-            int n = 1;
-            if (d >= tail_start) {
-                n = std::min(grp, P->max_depth - d);
+            if (d < tail_start) {
+                if (split) {
+                    sched.push_back({LK_SHADE, d, 1});
+                    if (d + 1 < P->max_depth && d + 1 < tail_start) sched.push_back({LK_TRACE, d + 1, 1});
+                } else {
+                    sched.push_back({LK_BOUNCE, d, 1});
+                }
+                d++;
+            } else {
+                const int n = std::min(grp, P->max_depth - d);
                 if (++rep == 2) { rep = 0; grp += grp / 2; }
+                sched.push_back({LK_BOUNCE, d, n});
+                d += n;
             }
-            sched.push_back({d, n});
-            d += n;
         }
+        // a batch must not end with probes still queued: a zero-bounce k_bounce resolves them and retires the zombies
+        if (!sched.empty() && sched.back().kind == LK_SHADE) sched.push_back({LK_BOUNCE, P->max_depth, 0});
+        split_first = split;
     }
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
     int rc = ensure_pool(c, (size_t)regions_max * region_cap, npix, cnt_words);
     if (rc) return rc;
-
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     HIP_TRY(c, hipEventCreate(&ev_begin));
     HIP_TRY(c, hipEventCreate(&ev_end));
@@ -864,8 +456,9 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             const size_t paths = npix * Sb;
             const uint32_t regions = (uint32_t)((paths + region_cap - 1) / region_cap);
             HIP_TRY_C(hipMemsetAsync(c->cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), s));
-            BounceArgs a{};
+            KArgs a{};
             a.sc = c->sc;
+            a.hit = c->hit;
             a.lbuf = c->lbuf;
             a.stats = c->d_stats;
             a.n_regions = regions;
@@ -879,6 +472,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             a.max_depth = (uint32_t)P->max_depth;
             a.stack_stride = kBlock;
             a.region_cap = (uint32_t)region_cap;
+            a.trace_first = split_first ? 1u : 0u;
             const uint32_t n_chunks = (uint32_t)((paths + kBlock - 1) / kBlock);
             const int grid = (int)std::min<uint32_t>(n_chunks, (uint32_t)c->n_cu * 8u);
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -887,21 +481,27 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             HIP_TRY_C(hipEventCreate(&e1));
             ev_loop.push_back(e1);
             HIP_TRY_C(hipEventRecord(e0, s));
-            for (size_t li = 0; li < sched.size(); li++) {
-                const int d = sched[li].first;
-                const int ib = (int)(li & 1), ob = ib ^ 1;  // launch li reads buffer li&1 (launch 0 reads nothing), writes the other
-                a.in0 = c->planes[ib][0]; a.in1 = c->planes[ib][1]; a.in2 = c->planes[ib][2]; a.in3 = c->plane3[ib];
-                a.out0 = c->planes[ob][0]; a.out1 = c->planes[ob][1]; a.out2 = c->planes[ob][2]; a.out3 = c->plane3[ob];
-                a.cnt_in = c->cnt + li * regions;
-                a.cnt_out = c->cnt + (li + 1) * regions;
-                a.depth = (uint32_t)d;
-                a.n_iter = (uint32_t)sched[li].second;
-                if (P->rng_kind == RTW_RNG_PHILOX) {
-                    if (d == 0) launch_bounce<RTW_RNG_PHILOX, true>(a, grid, lds, s);
-                    else launch_bounce<RTW_RNG_PHILOX, false>(a, grid, lds, s);
+            // k_first fills buffer 0 (and the hit buffer); every compacting launch then flips the buffers
+            int cur = 0;
+            size_t ci = 0;  // index of the region-counter row describing buffer `cur`
+            a.out = c->buf[0];
+            a.cnt_out = c->cnt;
+            a.depth = 0; a.n_iter = 1;
+            launch(LK_FIRST, P->rng_kind, a, grid, lds, s);
+            launches++;
+            for (const Step& st : sched) {
+                a.in = c->buf[cur];
+                a.cnt_in = c->cnt + ci * regions;
+                a.depth = (uint32_t)st.depth;
+                a.n_iter = (uint32_t)st.n_iter;
+                if (st.kind == LK_TRACE) {
+                    launch(LK_TRACE, P->rng_kind, a, grid, lds, s);
                 } else {
-                    if (d == 0) launch_bounce<RTW_RNG_TEA_LCG, true>(a, grid, lds, s);
-                    else launch_bounce<RTW_RNG_TEA_LCG, false>(a, grid, lds, s);
+                    a.out = c->buf[cur ^ 1];
+                    a.cnt_out = c->cnt + (ci + 1) * regions;
+                    launch(st.kind, P->rng_kind, a, grid, st.kind == LK_BOUNCE ? lds : 0, s);
+                    cur ^= 1;
+                    ci++;
                 }
                 launches++;
             }

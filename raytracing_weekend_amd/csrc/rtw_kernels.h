@@ -1,0 +1,645 @@
+// rtw_kernels.h — the wavefront kernels (gfx950). See rtw_hip.hip for the launch schedule.
+//
+//   k_first   generate primary rays (raygen.cu:123-147, camera.cu:11-19) and trace them
+//   k_shade   closest-hit / miss programs for one bounce of every live path: material scatter, light
+//             sampling (the shadow ray is QUEUED in the path state, not traced), Russian roulette,
+//             wave64 ballot/popcount compaction of the survivors into the other ping-pong buffer
+//   k_trace   lean, high-occupancy intersection pass over the compacted paths: the radiance ray's
+//             closest hit and the queued shadow ray's any-hit, both from the same origin
+//   k_bounce  fused trace+shade(+inline shadow probe) for several bounces in registers: the thin tail
+//             of a batch (latency-bound launches) and scenes whose intersection programs draw
+//             random numbers (volumes), where trace and shade cannot be separated
+//   k_resolve / k_finish   deterministic per-pixel sum of the sample slots, mean radiance
+//
+// Path state: six 16-byte SoA planes per path (96 B), read and written with dwordx4 accesses that
+// are contiguous across a wave:
+//   p0 = origin.xyz, dir.x      p1 = dir.yz, ray_time, gk (24-bit gather-time fraction | zombie bit 31)
+//   p2 = shadow dir.xyz, shadow tmax (<0: none queued)
+//   p3 = T.xyz, L.x             p4 = L.yz, c.xy          p5 = c.z, w0, rng a, rng b
+// c is the queued light-sample contribution (already multiplied by the throughput of its segment); it
+// is added to L by the next k_shade if the shadow probe found no occluder, before anything else
+// touches L, so the floating-point order of the reference's `sampleRadiance += radiance*throughput`
+// (raygen.cu:60) is preserved bit for bit. A "zombie" is a path that ended (roulette / depth) with a
+// shadow probe still queued: it survives one more trace pass, collects the contribution and retires.
+#pragma once
+#include "rtw_device.h"
+
+namespace rtwk {
+using namespace rtwdev;
+
+#ifndef RTW_MIN_WAVES
+#define RTW_MIN_WAVES 1
+#endif
+constexpr int kBlock = 256;                       // 4 wave64 per workgroup
+constexpr uint32_t kMinRegionCap = 64 * kBlock;   // a region holds at least 64 chunks of 256 paths
+constexpr uint32_t kMaxRegions = 2048;            // region counters scanned in LDS by every workgroup
+constexpr uint32_t kZombie = 0x80000000u;
+
+struct PathBuf {
+    float4* p0; float4* p1; float4* p2; float4* p3; float4* p4; uint4* p5;
+};
+
+struct KArgs {
+    DScene sc;
+    PathBuf in, out;
+    uint2* hit;                 // per input slot: t, (prim+1) | occluded<<31
+    float4* lbuf;               // per path id: final radiance of the sample
+    const uint32_t* cnt_in;     // live paths per region (input)
+    uint32_t* cnt_out;          // live paths per region (output), zeroed per batch
+    unsigned long long* stats;  // [0] segments, [1] shadow probes
+    uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, trace_first;
+};
+
+struct Path {
+    v3 o, d;
+    float ray_time;
+    uint32_t gk;
+    v3 ldir;
+    float ltmax;
+    v3 T, L, c;
+    uint32_t w0, a, b;
+};
+
+RTW_DEV void load_trace_part(const PathBuf& B, size_t s, Path& p) {
+    const float4 a = B.p0[s], b = B.p1[s], c = B.p2[s];
+    p.o = V(a.x, a.y, a.z); p.d = V(a.w, b.x, b.y); p.ray_time = b.z; p.gk = __float_as_uint(b.w);
+    p.ldir = V(c.x, c.y, c.z); p.ltmax = c.w;
+}
+RTW_DEV void load_path(const PathBuf& B, size_t s, Path& p) {
+    load_trace_part(B, s, p);
+    const float4 d = B.p3[s], e = B.p4[s];
+    const uint4 f = B.p5[s];
+    p.T = V(d.x, d.y, d.z); p.L = V(d.w, e.x, e.y); p.c = V(e.z, e.w, __uint_as_float(f.x));
+    p.w0 = f.y; p.a = f.z; p.b = f.w;
+}
+RTW_DEV void store_path(const PathBuf& B, size_t s, const Path& p) {
+    B.p0[s] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
+    B.p1[s] = make_float4(p.d.y, p.d.z, p.ray_time, __uint_as_float(p.gk));
+    B.p2[s] = make_float4(p.ldir.x, p.ldir.y, p.ldir.z, p.ltmax);
+    B.p3[s] = make_float4(p.T.x, p.T.y, p.T.z, p.L.x);
+    B.p4[s] = make_float4(p.L.y, p.L.z, p.c.x, p.c.y);
+    B.p5[s] = make_uint4(__float_as_uint(p.c.z), p.w0, p.a, p.b);
+}
+
+// ------------------------------------------------------------------ work list
+// Region r holds cnt_in[r] live paths = ceil(cnt/256) chunks. Every workgroup scans the (<= kMaxRegions)
+// counters into an LDS prefix array once, then strides over the virtual chunk ids: no empty
+// iterations, perfect balance, and a launch with nothing alive costs one scan.
+struct WorkList {
+    uint32_t* pref;  // [kMaxRegions+1] exclusive prefix of chunk counts
+    uint32_t* raw;   // [kMaxRegions]
+    uint32_t total_chunks;
+};
+#define RTW_WORKLIST_SHARED                        \
+    __shared__ uint32_t s_pref[kMaxRegions + 1];   \
+    __shared__ uint32_t s_raw[kMaxRegions];        \
+    __shared__ uint32_t s_part[kBlock];
+
+RTW_DEV WorkList worklist_init(const uint32_t* cnt_in, uint32_t n_regions, uint32_t* s_pref, uint32_t* s_raw, uint32_t* s_part) {
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t kPer = kMaxRegions / kBlock;
+    uint32_t loc[kPer];
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; j++) {
+        const uint32_t r = tid * kPer + j;
+        const uint32_t raw = r < n_regions ? cnt_in[r] : 0u;
+        s_raw[r] = raw;
+        loc[j] = sum;
+        sum += (raw + kBlock - 1) / kBlock;
+    }
+    s_part[tid] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < kBlock; off <<= 1) {
+        const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    const uint32_t excl = s_part[tid] - sum;
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; j++) s_pref[tid * kPer + j] = excl + loc[j];
+    if (tid == kBlock - 1) s_pref[kMaxRegions] = s_part[tid];
+    __syncthreads();
+    WorkList w;
+    w.pref = s_pref; w.raw = s_raw; w.total_chunks = s_pref[kMaxRegions];
+    return w;
+}
+RTW_DEV void worklist_lookup(const WorkList& w, uint32_t n_regions, uint32_t vc, uint32_t& region, uint32_t& chunk, uint32_t& n_in) {
+    uint32_t lo = 0, hi = n_regions;  // largest r with pref[r] <= vc
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (w.pref[mid] <= vc) lo = mid; else hi = mid;
+    }
+    region = lo;
+    chunk = vc - w.pref[lo];
+    n_in = w.raw[lo];
+}
+
+// ------------------------------------------------------------------ shading
+struct Nee {
+    bool has;
+    v3 dir, rad;  // rad = f * Le * (w * (wL.n) / pdfL), not yet multiplied by the throughput
+    float tmin, tmax;
+};
+
+// Closest-hit / miss program up to and including the light sample (shaders/closehit.cu:45-94,
+// miss/miss.cu:8-30, material/*.cu, pdf/mixturePdf.cu:25-38, pdf/rectPdf.cu:124-193).
+template <int KIND>
+RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 dir, const float gather_time, const float t, const int prim,
+                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee) {
+    radiance = V(0.f, 0.f, 0.f);
+    att = V(0.f, 0.f, 0.f);
+    so = origin; sd = dir;
+    nee.has = false;
+    nee.dir = V(0.f, 0.f, 0.f); nee.rad = V(0.f, 0.f, 0.f); nee.tmin = 0.f; nee.tmax = -1.f;
+    if (prim < 0) {
+        if (sc.sky_light) {  // miss.cu:8-21
+            v3 u = normalize3(dir);
+            float tt = 0.5f * (u.y + 1.0f);
+            float w = 1.0f - tt;
+            radiance = V(fma_(tt, 0.5f, w), fma_(tt, 0.7f, w), fma_(tt, 1.0f, w));
+        }
+        return EV_MISS;
+    }
+    const HitRec hr = load_hitrec(sc, prim);
+    v3 hp, hn;
+    hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
+    const int mtype = hr.mat_type;
+    const float mparam = hr.param;
+    const v3 tex = V(hr.r, hr.g, hr.b);
+    int ev;
+    bool specular = false;
+    if (mtype == RTW_MAT_LAMBERTIAN) {
+        // lambertianMaterial.cu:41-71, onb.cuh:20-32, sampling.cuh:49-60 (Q1)
+        v3 w = normalize3(hn);
+        v3 a = (w.x > 0.9f || w.x < -0.9f) ? V(0.f, 1.f, 0.f) : V(1.f, 0.f, 0.f);
+        v3 v = normalize3(cross3(w, a));
+        v3 u = cross3(w, v);
+        float r1 = g.next1();
+        float r2 = g.next1();
+        float sn, cs;
+        sincos2pi(r1, sn, cs);
+        float sq = __builtin_sqrtf(r2);
+        float lx = (cs * 2.0f) * sq;
+        float ly = (sn * 2.0f) * sq;
+        float lz = __builtin_sqrtf(1.0f - r2);
+        float pdf = lz * RTW_1_PI_F;
+        v3 sdir = V(fma_(lz, w.x, fma_(ly, v.x, lx * u.x)),
+                    fma_(lz, w.y, fma_(ly, v.y, lx * u.y)),
+                    fma_(lz, w.z, fma_(ly, v.z, lx * u.z)));
+        sdir = normalize3(sdir);
+        so = hp; sd = sdir;
+        float cosine = dot3(hn, sdir);
+        ev = EV_HIT;
+        if (cosine <= 0.0f || pdf <= 0.0f) ev = EV_CANCEL;
+        else att = tex;
+    } else if (mtype == RTW_MAT_DIFFUSE_LIGHT) {
+        // diffuseLight.cu:48-69
+        if (dot3(hn, dir) < 0.0f) radiance = tex;
+        ev = EV_CANCEL;
+    } else if (mtype == RTW_MAT_METAL) {
+        // metalMaterial.cu:32-64 (Q5)
+        specular = true;
+        v3 refl = reflect3(dir, hn);
+        v3 ball = random_in_unit_sphere(g);
+        v3 sdir = normalize3(vfma(ball, mparam, refl));
+        so = hp; sd = sdir;
+        att = tex;
+        ev = (dot3(sdir, hn) <= 0.0f) ? EV_CANCEL : EV_HIT;
+    } else if (mtype == RTW_MAT_DIELECTRIC) {
+        // dielectricMaterial.cu:37-114
+        specular = true;
+        v3 unit = normalize3(dir);
+        v3 ln;
+        float eta_i, eta_t;
+        if (dot3(dir, hn) < 0.0f) { ln = hn; eta_i = 1.0f; eta_t = mparam; }
+        else { ln = vneg(hn); eta_i = mparam; eta_t = 1.0f; }
+        float cos_i = __builtin_fminf(dot3(vneg(unit), ln), 1.0f);
+        float sin_i = __builtin_sqrtf(fma_(-cos_i, cos_i, 1.0f));
+        float ratio = eta_i / eta_t;
+        v3 sdir;
+        if (ratio * sin_i > 1.0f) {
+            sdir = reflect3(unit, ln);
+        } else {
+            float r0 = (eta_i - eta_t) / (eta_i + eta_t);
+            r0 = r0 * r0;
+            float om = 1.0f - cos_i;
+            float om2 = om * om;
+            float p5 = (om2 * om2) * om;
+            float refl_prob = fma_(1.0f - r0, p5, r0);
+            if (g.next1() < refl_prob) {
+                sdir = reflect3(unit, ln);
+            } else {
+                float sin_t = __builtin_fminf(ratio * sin_i, 1.0f);
+                float cos_t = __builtin_sqrtf(fma_(-sin_t, sin_t, 1.0f));
+                v3 a = vscale(vfma(ln, cos_i, unit), ratio);
+                sdir = vfma(ln, -cos_t, a);
+            }
+        }
+        so = hp; sd = sdir;
+        att = V(1.f, 1.f, 1.f);
+        ev = EV_HIT;
+    } else if (mtype == RTW_MAT_ISOTROPIC) {
+        // isotropicMaterial.cu:30-51 (Q14)
+        specular = true;
+        sd = random_in_unit_sphere(g);
+        so = hp;
+        att = tex;
+        ev = EV_HIT;
+    } else {
+        // normalMaterial.cu:21-31
+        specular = true;
+        att = vfma(hn, 0.5f, V(0.5f, 0.5f, 0.5f));
+        ev = EV_FINISH;
+    }
+
+    // next-event estimation, closehit.cu:70-94: sample the light; the visibility probe comes later
+    const int nl = sc.n_lights;
+    if (ev == EV_HIT && !specular && nl > 0) {
+        int il = 0;
+        if (nl > 1) {
+            il = (int)__builtin_floorf(g.next1() * (float)nl);
+            il = il < 0 ? 0 : (il > nl - 1 ? nl - 1 : il);
+        }
+        // one light (the usual case): the record index is wave-uniform, so it is read through the scalar cache
+        v3 lnrm, lemi;
+        float larea;
+        if (nl > 1) {
+            const RTW_CONST rtw_light* lt = as_const(sc.lights + il);
+            lnrm = V(lt->normal[0], lt->normal[1], lt->normal[2]);
+            lemi = V(lt->emission[0], lt->emission[1], lt->emission[2]);
+            larea = lt->area;
+        } else {
+            const RTW_CONST rtw_light* lt = as_const(sc.lights);
+            lnrm = V(lt->normal[0], lt->normal[1], lt->normal[2]);
+            lemi = V(lt->emission[0], lt->emission[1], lt->emission[2]);
+            larea = lt->area;
+        }
+        int gen = sc.pdf.gen;  // mixturePdf.cu:25-38: always child p1 (Q4)
+        if (gen == RTW_PDF_MIXTURE || gen == RTW_PDF_MIXTURE_BIAS) gen = sc.pdf.p1_gen;
+        float lpdf = 0.0f, ldist = 0.0f;
+        v3 ldir = V(0.f, 0.f, 0.f), lem = V(0.f, 0.f, 0.f);
+        if (gen == RTW_PDF_RECT_X || gen == RTW_PDF_RECT_Y || gen == RTW_PDF_RECT_Z) {
+            // rectPdf.cu:124-193
+            float ra = g.next1();
+            float rb = g.next1();
+            float pa = fma_(ra, sc.pdf.rect[1] - sc.pdf.rect[0], sc.pdf.rect[0]);
+            float pb = fma_(rb, sc.pdf.rect[3] - sc.pdf.rect[2], sc.pdf.rect[2]);
+            float k = sc.pdf.rect[4];
+            v3 rp = (gen == RTW_PDF_RECT_X) ? V(k, pa, pb) : (gen == RTW_PDF_RECT_Y) ? V(pa, k, pb) : V(pa, pb, k);
+            ldir = vsub(rp, so);
+            ldist = length3(ldir);
+            if (ldist > 1.0e-6f) {
+                ldir = vscale(ldir, 1.0f / ldist);
+                float costa = dot3(vneg(ldir), lnrm);
+                if (costa > 1.0e-6f) {
+                    lem = vscale(lemi, (float)nl);
+                    lpdf = (ldist * ldist) / (larea * costa);
+                }
+            }
+        }
+        if (lpdf > 0.0f && hr.bsdf_eval == 0) {
+            // lambertianMaterial.cu:74-81
+            v3 f = vscale(att, RTW_1_PI_F);
+            float ndl = dot3(ldir, hn);
+            float bpdf = __builtin_fmaxf(0.0f, ndl * RTW_1_PI_F);
+            if (0.0f < bpdf && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f)) {
+                const float eps = 500 * 1.0e-7f;
+                float a2 = lpdf * lpdf;
+                float weight = a2 / fma_(bpdf, bpdf, a2);  // raydata.cuh:167-171
+                float k = (weight * ndl) / lpdf;
+                nee.has = true;
+                nee.dir = ldir;
+                nee.tmin = eps;
+                nee.tmax = ldist - eps;  // closehit.cu:95-101
+                nee.rad = vscale(vmul(f, lem), k);  // closehit.cu:111-113
+            }
+        }
+    }
+    return ev;
+}
+
+// Tail of rayColor's loop body (raygen.cu:60-84): accumulate, continue or stop, Russian roulette.
+template <int KIND>
+RTW_DEV bool shade_b(const uint32_t depth, const uint32_t max_depth, Rng<KIND>& g, const int ev, const v3 so, const v3 sd, const v3 att,
+                     const v3 radiance, v3& origin, v3& dir, v3& T, v3& L) {
+    L = vadd(L, vmul(radiance, T));  // raygen.cu:60
+    if (ev != EV_HIT) return false;
+    origin = so; dir = sd;
+    T = vmul(T, att);
+    if (2u <= depth) {  // raygen.cu:74-82
+        float p = __builtin_fmaxf(__builtin_fmaxf(T.x, T.y), T.z);
+        if (p < g.next1()) return false;
+        T = vscale(T, 1.0f / p);
+    }
+    return depth + 1u < max_depth;
+}
+
+template <int KIND>
+RTW_DEV void rng_from_path(Rng<KIND>& g, uint32_t seed, const Path& p) {
+    if (KIND == RTW_RNG_TEA_LCG) g.init(seed, 0, 0, p.a, p.b);
+    else g.init(seed, p.w0, p.b, p.a, p.b);  // Philox: w0 = global pixel, b = sample index
+}
+template <int KIND>
+RTW_DEV uint32_t path_id_of(const KArgs& A, const Path& p) {
+    if (KIND == RTW_RNG_TEA_LCG) return p.w0;
+    return (p.b - A.sample0) * A.npix + (p.w0 - A.row0 * A.width);
+}
+RTW_DEV float gather_time_of(const KArgs& A, uint32_t gk) {
+    return fma_((float)(gk & 0x00ffffffu) * (1.0f / 16777216.0f), A.sc.cam.time1 - A.sc.cam.time0, A.sc.cam.time0);
+}
+RTW_DEV void finish_path(const KArgs& A, uint32_t path_id, v3 L) {
+    // removeNaNs, raygen.cu:17-24
+    float lx = (L.x == L.x) ? L.x : 0.f, ly = (L.y == L.y) ? L.y : 0.f, lz = (L.z == L.z) ? L.z : 0.f;
+    A.lbuf[path_id] = make_float4(lx, ly, lz, 0.f);
+}
+// wave64 ballot + popcount prefix; one atomic per wave reserves its slice of the region's output
+RTW_DEV void compact_store(const KArgs& A, uint32_t region, bool keep, const Path& p) {
+    const unsigned long long ballot = __ballot(keep);
+    if (!ballot) return;
+    const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
+    uint32_t base = 0;
+    if ((threadIdx.x & 63u) == 0) base = atomicAdd(&A.cnt_out[region], (uint32_t)__popcll(ballot));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (keep) store_path(A.out, (size_t)region * A.region_cap + base + before, p);
+}
+RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow) {
+    for (int off = 32; off > 0; off >>= 1) {
+        n_seg += __shfl_down(n_seg, off);
+        n_shadow += __shfl_down(n_shadow, off);
+    }
+    if ((threadIdx.x & 63u) == 0 && (n_seg | n_shadow)) {
+        atomicAdd(&A.stats[0], (unsigned long long)n_seg);
+        atomicAdd(&A.stats[1], (unsigned long long)n_shadow);
+    }
+}
+
+struct NoRng {
+    uint32_t a, b;
+    RTW_DEV float next1() { return 0.5f; }
+    RTW_DEV float randf1() { return 0.5f; }
+};
+
+// ------------------------------------------------------------------ k_first
+template <int KIND>
+__global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
+    extern __shared__ uint32_t s_stack[];
+    const uint32_t tid = threadIdx.x;
+    if (blockIdx.x == 0)
+        for (uint32_t r = tid; r < A.n_regions; r += kBlock) {
+            const uint32_t lo = r * A.region_cap;
+            A.cnt_out[r] = A.n_paths > lo ? min(A.region_cap, A.n_paths - lo) : 0u;
+        }
+    const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
+    for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
+        const uint32_t path_id = vc * kBlock + tid;
+        if (path_id >= A.n_paths) continue;
+        // __raygen__Program (raygen.cu:123-147) + perspectiveCamera (camera.cu:11-19) + color() (raygen.cu:89-95)
+        const uint32_t slot = path_id / A.npix;
+        const uint32_t pl = path_id - slot * A.npix;
+        const uint32_t yl = pl / A.width;
+        const uint32_t x = pl - yl * A.width;
+        const uint32_t y = A.row0 + yl;
+        const uint32_t pixel = A.width * y + x;
+        const uint32_t sample = A.sample0 + slot;
+        Path p;
+        Rng<KIND> g;
+        float r0, r1, r2, r3, r4;
+        if (KIND == RTW_RNG_TEA_LCG) {
+            uint32_t s = tea<64>(pixel, sample);  // raygen.cu:129
+            r0 = lcg_rnd(s); r1 = lcg_rnd(s); r2 = lcg_rnd(s); r3 = lcg_rnd(s);
+            g.init(A.seed, pixel, sample, s, s);  // prd.seed = seed; rayColor's local copy (Q7)
+            r4 = lcg_rnd(s);
+            p.w0 = path_id;
+        } else {
+            uint32_t o[4];
+            philox4x32_10(pixel, sample, 0u, 0u, A.seed, 0u, o);
+            r0 = u24(o[0]); r1 = u24(o[1]); r2 = u24(o[2]); r3 = u24(o[3]);
+            philox4x32_10(pixel, sample, 1u, 0u, A.seed, 0u, o);
+            r4 = u24(o[0]);
+            g.init(A.seed, pixel, sample, 0u, sample);
+            p.w0 = pixel;
+        }
+        const rtw_camera& cam = A.sc.cam;
+        const float s = ((float)x + r0) / (float)A.width;
+        const float t = ((float)y + r1) / (float)A.height;
+        p.o = ld3(cam.origin);
+        if (cam.lens_radius != 0.0f) {  // sampling.cuh:15-22; the two draws are consumed either way
+            float sn, cs;
+            sincos2pi(r2, sn, cs);
+            float sq = __builtin_sqrtf(r3);
+            float rx = cam.lens_radius * (sn * sq);
+            float ry = cam.lens_radius * (cs * sq);
+            p.o = vadd(p.o, vfma(ld3(cam.v), ry, vscale(ld3(cam.u), rx)));
+        }
+        p.d = vfma(ld3(cam.horizontal), s, ld3(cam.lower_left));
+        p.d = vfma(ld3(cam.vertical), t, p.d);
+        p.d = vsub(p.d, p.o);
+        p.gk = (uint32_t)(r4 * 16777216.0f);
+        p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(0u) : 0.0f;  // raygen.cu:48
+        p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;
+        p.T = V(1.f, 1.f, 1.f); p.L = V(0.f, 0.f, 0.f); p.c = V(0.f, 0.f, 0.f);
+        p.a = g.a; p.b = g.b;
+        store_path(A.out, path_id, p);
+        if (A.trace_first) {
+            float th;
+            int prim;
+            NoRng ng;
+            traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gather_time_of(A, p.gk), ng, s_stack + tid, A.stack_stride, th, prim);
+            A.hit[path_id] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1));
+        }
+    }
+}
+
+// ------------------------------------------------------------------ k_trace
+// Only scenes without volume primitives reach this kernel, so no intersection program draws random numbers.
+__global__ void __launch_bounds__(kBlock, 8) k_trace(const KArgs A) {
+    extern __shared__ uint32_t s_stack[];
+    RTW_WORKLIST_SHARED
+    const uint32_t tid = threadIdx.x;
+    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
+    for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
+        uint32_t region, chunk, n_in;
+        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_in);
+        const uint32_t idx = chunk * kBlock + tid;
+        if (idx >= n_in) continue;
+        const size_t slot = (size_t)region * A.region_cap + idx;
+        Path p;
+        load_trace_part(A.in, slot, p);
+        NoRng ng;
+        const float gt = gather_time_of(A, p.gk);
+        float th = 0.f;
+        int prim = -1;
+        if (!(p.gk & kZombie))
+            traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, s_stack + tid, A.stack_stride, th, prim);
+        uint32_t occl = 0;
+        if (p.ltmax >= 0.0f) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
+            float st;
+            int sprim;
+            traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, s_stack + tid, A.stack_stride, st, sprim);
+            occl = sprim >= 0 ? 0x80000000u : 0u;
+        }
+        A.hit[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
+    }
+}
+
+// ------------------------------------------------------------------ k_shade
+template <int KIND>
+__global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_shade(const KArgs A) {
+    RTW_WORKLIST_SHARED
+    const uint32_t tid = threadIdx.x;
+    uint32_t n_seg = 0, n_shadow = 0;
+    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
+    for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
+        uint32_t region, chunk, n_in;
+        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_in);
+        const uint32_t idx = chunk * kBlock + tid;
+        const bool valid = idx < n_in;
+        bool keep = false;
+        Path p;
+        p.gk = 0; p.ltmax = -1.f;
+        if (valid) {
+            const size_t slot = (size_t)region * A.region_cap + idx;
+            load_path(A.in, slot, p);
+            const uint2 h = A.hit[slot];
+            // the light sample queued by the previous bounce (closehit.cu:103-113), now that its probe is back
+            if (p.ltmax >= 0.0f && !(h.y & 0x80000000u)) p.L = vadd(p.L, p.c);
+            if (p.gk & kZombie) {
+                finish_path(A, path_id_of<KIND>(A, p), p.L);
+            } else {
+                Rng<KIND> g;
+                rng_from_path<KIND>(g, A.seed, p);
+                const float gt = gather_time_of(A, p.gk);
+                const int prim = (int)(h.y & 0x7fffffffu) - 1;
+                v3 so, sd, att, radiance;
+                Nee nee;
+                const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, __uint_as_float(h.x), prim, so, sd, att, radiance, nee);
+                n_seg++;
+                p.ltmax = -1.0f;
+                if (nee.has) {
+                    p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T);
+                    n_shadow++;
+                }
+                const bool alive = shade_b<KIND>(A.depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L);
+                if (ev == EV_HIT) p.o = so;  // a queued probe starts at the hit point even when the path stops here
+                p.a = g.a; p.b = g.b;
+                if (alive) {
+                    p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(A.depth + 1u) : 0.0f;
+                    p.b = g.b;
+                    keep = true;
+                } else if (nee.has) {
+                    p.gk |= kZombie;
+                    keep = true;
+                } else {
+                    finish_path(A, path_id_of<KIND>(A, p), p.L);
+                }
+            }
+        }
+        compact_store(A, region, keep, p);
+    }
+    flush_stats(A, n_seg, n_shadow);
+}
+
+// ------------------------------------------------------------------ k_bounce (fused)
+template <int KIND>
+__global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A) {
+    extern __shared__ uint32_t s_stack[];
+    RTW_WORKLIST_SHARED
+    const uint32_t tid = threadIdx.x;
+    uint32_t* my_stack = s_stack + tid;
+    uint32_t n_seg = 0, n_shadow = 0;
+    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
+    for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
+        uint32_t region, chunk, n_in;
+        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_in);
+        const uint32_t idx = chunk * kBlock + tid;
+        const bool valid = idx < n_in;
+        bool keep = false;
+        Path p;
+        p.gk = 0; p.ltmax = -1.f;
+        if (valid) {
+            load_path(A.in, (size_t)region * A.region_cap + idx, p);
+            Rng<KIND> g;
+            rng_from_path<KIND>(g, A.seed, p);
+            const float gt = gather_time_of(A, p.gk);
+            if (p.ltmax >= 0.0f) {  // a probe queued by k_shade: resolve it here
+                float st;
+                int sprim;
+                traverse<Rng<KIND>, true, false>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, g, my_stack, A.stack_stride, st, sprim);
+                if (sprim < 0) p.L = vadd(p.L, p.c);
+                p.ltmax = -1.0f;
+            }
+            if (p.gk & kZombie) {
+                finish_path(A, path_id_of<KIND>(A, p), p.L);
+            } else {
+                // A.n_iter consecutive bounces in registers: the thin tail of a batch is latency-bound, so fewer,
+                // longer launches win; scenes with volumes run every bounce here (n_iter = 1 while wide).
+                uint32_t depth = A.depth;
+                bool alive = false;
+                for (uint32_t it = 0; it < A.n_iter; it++) {
+                    float t;
+                    int prim;
+                    traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, g, my_stack, A.stack_stride, t, prim);
+                    v3 so, sd, att, radiance;
+                    Nee nee;
+                    const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, t, prim, so, sd, att, radiance, nee);
+                    n_seg++;
+                    if (nee.has) {
+                        float st;
+                        int sprim;
+                        traverse<Rng<KIND>, true, false>(A.sc, so, nee.dir, nee.tmin, nee.tmax, 0.0f, gt, g, my_stack, A.stack_stride, st, sprim);
+                        n_shadow++;
+                        if (sprim < 0) radiance = vadd(radiance, nee.rad);
+                    }
+                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L);
+                    depth++;
+                    if (!alive) break;
+                    p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(depth) : 0.0f;
+                }
+                p.a = g.a; p.b = g.b;
+                if (alive) keep = true;
+                else finish_path(A, path_id_of<KIND>(A, p), p.L);
+            }
+        }
+        compact_store(A, region, keep, p);
+    }
+    flush_stats(A, n_seg, n_shadow);
+}
+
+// sums the S sample slots of every pixel in ascending sample order (fixed order => reproducible bits)
+__global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ lbuf, float4* __restrict__ accum, uint32_t npix, uint32_t nslots) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        float4 a = accum[i];
+        for (uint32_t s = 0; s < nslots; s++) {
+            float4 l = lbuf[(size_t)s * npix + i];
+            a.x += l.x; a.y += l.y; a.z += l.z;
+        }
+        accum[i] = a;
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_finish(const float4* __restrict__ accum, float4* __restrict__ out, uint32_t npix, float spp) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        float4 a = accum[i];
+        out[i] = make_float4(a.x / spp, a.y / spp, a.z / spp, 1.0f);
+    }
+}
+
+__global__ void __launch_bounds__(kBlock) k_debug_intersect(const DScene sc, const float* __restrict__ rays, const float* __restrict__ ray_time,
+                                                           const float* __restrict__ gather_time, int n, float* __restrict__ out_t,
+                                                           int32_t* __restrict__ out_prim, uint32_t stack_stride) {
+    extern __shared__ uint32_t s_stack[];
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = rays + 8 * (size_t)i;
+    NoRng g;
+    float t;
+    int prim;
+    traverse<NoRng, false, true>(sc, V(r[0], r[1], r[2]), V(r[3], r[4], r[5]), r[6], r[7], ray_time ? ray_time[i] : 0.f,
+                                 gather_time ? gather_time[i] : 0.f, g, s_stack + threadIdx.x, stack_stride, t, prim);
+    out_t[i] = t;
+    out_prim[i] = prim;
+}
+
+}  // namespace rtwk
