@@ -466,15 +466,23 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
             int ri = G.first;
             if (G.n_rx + G.n_ry + G.n_rz > 0) {
                 const v3 inv = recip3(dd);
+// straight-line candidate test: every comparison is evaluated, the update is one predicated select
+#define RTW_TAKE(HIT_, T_, PI_)                                                                      \
+                {                                                                                    \
+                    const bool tie_ = !ANY_HIT && ((T_) == best_t) & ((PI_) < best_prim) & !best_is_vol; \
+                    const bool take_ = (HIT_) & (((T_) < best_t) | tie_);                            \
+                    best_t = take_ ? (T_) : best_t;                                                  \
+                    best_prim = take_ ? (PI_) : best_prim;                                           \
+                    best_is_vol = take_ ? false : best_is_vol;                                       \
+                }
 #define RTW_RECT_LOOP(N_, OK_, IK_, OA_, DA_, OB_, DB_)                                              \
                 for (int i = 0; i < (N_); i++, ri++) {                                               \
                     const BruteRec R = load_rec(sc, ri);                                             \
                     const float t = (R.e - (OK_)) * (IK_);                                           \
-                    if (!(t >= tmin)) continue;                                                      \
                     const float a = fma_(t, (DA_), (OA_));                                           \
                     const float b = fma_(t, (DB_), (OB_));                                           \
-                    if (!(a >= R.a && a <= R.b && b >= R.c && b <= R.d)) continue;                   \
-                    RTW_ACCEPT(t, R.prim)                                                            \
+                    const bool hit = (t >= tmin) & (a >= R.a) & (a <= R.b) & (b >= R.c) & (b <= R.d); \
+                    RTW_TAKE(hit, t, R.prim)                                                         \
                 }
                 RTW_RECT_LOOP(G.n_rx, oo.x, inv.x, oo.y, dd.y, oo.z, dd.z)   // shaders/aarectx.cu:8-22
                 RTW_RECT_LOOP(G.n_ry, oo.y, inv.y, oo.x, dd.x, oo.z, dd.z)   // shaders/aarecty.cu:8-22
@@ -483,9 +491,11 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
             }
             for (int i = 0; i < G.n_sph; i++, ri++) {
                 const BruteRec R = load_rec(sc, ri);
-                float t;
-                if (sphere_roots(oo, dd, V(R.a, R.b, R.c), R.d, tmin, RTW_FLT_MAX, t)) { RTW_ACCEPT(t, R.prim) }
+                float t = 0.f;
+                const bool hit = sphere_roots(oo, dd, V(R.a, R.b, R.c), R.d, tmin, RTW_FLT_MAX, t);
+                RTW_TAKE(hit, t, R.prim)
             }
+#undef RTW_TAKE
         }
         // moving spheres (own motion transform per candidate): generic path
         for (int k = 0; k < sc.n_generic; k++) {

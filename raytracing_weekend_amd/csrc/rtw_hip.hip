@@ -406,8 +406,8 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         while (d < P->max_depth) {
             if (d < tail_start) {
                 if (split) {
-                    sched.push_back({LK_SHADE, d, 1});
-                    if (d + 1 < P->max_depth && d + 1 < tail_start) sched.push_back({LK_TRACE, d + 1, 1});
+                    // k_first has already traced and shaded depth 0
+                    if (d > 0) { sched.push_back({LK_TRACE, d, 1}); sched.push_back({LK_SHADE, d, 1}); }
                 } else {
                     sched.push_back({LK_BOUNCE, d, 1});
                 }
@@ -420,7 +420,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             }
         }
         // a batch must not end with probes still queued: a zero-bounce k_bounce resolves them and retires the zombies
-        if (!sched.empty() && sched.back().kind == LK_SHADE) sched.push_back({LK_BOUNCE, P->max_depth, 0});
+        if (split && (sched.empty() || sched.back().kind == LK_SHADE)) sched.push_back({LK_BOUNCE, P->max_depth, 0});
         split_first = split;
     }
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);

@@ -386,15 +386,15 @@ template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
-    if (blockIdx.x == 0)
-        for (uint32_t r = tid; r < A.n_regions; r += kBlock) {
-            const uint32_t lo = r * A.region_cap;
-            A.cnt_out[r] = A.n_paths > lo ? min(A.region_cap, A.n_paths - lo) : 0u;
-        }
+    uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
     for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
         const uint32_t path_id = vc * kBlock + tid;
-        if (path_id >= A.n_paths) continue;
+        const uint32_t path_region = (vc * kBlock) / A.region_cap;  // region_cap is a multiple of the chunk size
+        bool keep = false;
+        Path p;
+        p.gk = 0; p.ltmax = -1.f;
+        if (path_id < A.n_paths) {
         // __raygen__Program (raygen.cu:123-147) + perspectiveCamera (camera.cu:11-19) + color() (raygen.cu:89-95)
         const uint32_t slot = path_id / A.npix;
         const uint32_t pl = path_id - slot * A.npix;
@@ -403,7 +403,6 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
         const uint32_t y = A.row0 + yl;
         const uint32_t pixel = A.width * y + x;
         const uint32_t sample = A.sample0 + slot;
-        Path p;
         Rng<KIND> g;
         float r0, r1, r2, r3, r4;
         if (KIND == RTW_RNG_TEA_LCG) {
@@ -441,15 +440,40 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
         p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;
         p.T = V(1.f, 1.f, 1.f); p.L = V(0.f, 0.f, 0.f); p.c = V(0.f, 0.f, 0.f);
         p.a = g.a; p.b = g.b;
-        store_path(A.out, path_id, p);
+        keep = true;
         if (A.trace_first) {
+            // split pipeline: trace and shade the primary segment here (primary rays are coherent, so the fused
+            // form costs no divergence and saves writing and re-reading 104 B per camera path, half of which
+            // leave the scene at once in a 16:9 Cornell frame)
             float th;
             int prim;
             NoRng ng;
-            traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gather_time_of(A, p.gk), ng, s_stack + tid, A.stack_stride, th, prim);
-            A.hit[path_id] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1));
+            const float gt = gather_time_of(A, p.gk);
+            traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, s_stack + tid, A.stack_stride, th, prim);
+            v3 so, sd, att, radiance;
+            Nee nee;
+            const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
+            n_seg++;
+            if (nee.has) {
+                p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T);
+                n_shadow++;
+            }
+            const bool alive = shade_b<KIND>(0u, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L);
+            p.a = g.a; p.b = g.b;
+            if (alive) {
+                p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(1u) : 0.0f;
+                p.b = g.b;
+            } else if (nee.has) {
+                p.gk |= kZombie;
+            } else {
+                finish_path(A, path_id, p.L);
+                keep = false;
+            }
         }
+        }
+        compact_store(A, path_region, keep, p);
     }
+    flush_stats(A, n_seg, n_shadow);
 }
 
 // ------------------------------------------------------------------ k_trace
