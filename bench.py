@@ -23,24 +23,30 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 
 
 def cpu_baseline(blob, abi):
-    """CPU oracle (oracle/rtw_oracle.c, 'port') on a bounded sample of the same workload: the full
-    1920x1080 frame at depth 50, few spp, timed on this host's cores. Baseline only."""
+    """CPU oracle (oracle/rtw_oracle.c, kind "port") timed on this host's cores on a BOUNDED sample of
+    the same workload: the full 1920x1080 frame at depth 50, at the few spp that take about 10 s.
+    Baseline only: it says nothing about kernel quality (the roofline fraction does)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle  # the checker; used here only as the timed CPU baseline
     cores = max(1, min(os.cpu_count() or 1, 64))
-    # single thread: a 1920x135 band at 1 spp (259k samples), all threads: full frame at 2 spp
-    p1 = abi.make_params(WIDTH, HEIGHT, 1, DEPTH, seed=SEED, row0=472, row1=607)
-    t = time.perf_counter()
-    _, s1 = oracle.render(blob, p1, threads=1)
-    dt1 = time.perf_counter() - t
-    pn = abi.make_params(WIDTH, HEIGHT, 2, DEPTH, seed=SEED)
-    t = time.perf_counter()
-    _, sn = oracle.render(blob, pn, threads=cores)
-    dtn = time.perf_counter() - t
+
+    def timed(p, threads):
+        t = time.perf_counter()
+        _, st = oracle.render(blob, p, threads=threads)
+        return st, time.perf_counter() - t
+
+    # calibrate on one spp, then size each timed run to ~10 s of wall time
+    st, dt = timed(abi.make_params(WIDTH, HEIGHT, 1, DEPTH, seed=SEED), cores)
+    spp_n = int(max(1, min(256, round(10.0 / max(dt, 1e-3)))))
+    sn, dtn = timed(abi.make_params(WIDTH, HEIGHT, spp_n, DEPTH, seed=SEED), cores)
+    band = (472, 607)  # 135 rows through the middle of the frame
+    st1, dt1 = timed(abi.make_params(WIDTH, HEIGHT, 1, DEPTH, seed=SEED, row0=band[0], row1=band[1]), 1)
+    spp_1 = int(max(1, min(256, round(10.0 / max(dt1, 1e-3)))))
+    s1, dt1 = timed(abi.make_params(WIDTH, HEIGHT, spp_1, DEPTH, seed=SEED, row0=band[0], row1=band[1]), 1)
     return {
         "value": round(sn.samples / dtn / 1e6, 4), "unit": "Msamples/s", "cores": cores, "kind": "port",
-        "sample": f"Cornell box {WIDTH}x{HEIGHT}, 2 spp, depth {DEPTH}, {cores} threads ({dtn:.1f} s); "
-                  f"single thread: rows 472-606 at 1 spp = {s1.samples / dt1 / 1e6:.4f} Msamples/s ({dt1:.1f} s)",
+        "sample": f"Cornell box {WIDTH}x{HEIGHT}, {spp_n} spp, depth {DEPTH}, {cores} threads, {dtn:.1f} s; "
+                  f"single thread: rows {band[0]}-{band[1] - 1} at {spp_1} spp, {dt1:.1f} s",
         "single_thread_value": round(s1.samples / dt1 / 1e6, 4),
         "segments_per_sample": round(sn.segments / sn.samples, 4),
     }
@@ -74,7 +80,8 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     blob = abi.build_scene(0, WIDTH, HEIGHT)
-    rows = [(g * HEIGHT) // world for g in range(world + 1)]
+    from raytracing_weekend_amd.dist import partition_rows
+    rows = partition_rows(HEIGHT, world)
     row0, row1 = rows[rank], rows[rank + 1]
     max_rows = max(rows[g + 1] - rows[g] for g in range(world))
     params = abi.make_params(WIDTH, HEIGHT, args.spp, DEPTH, seed=SEED, row0=row0, row1=row1, rng_kind=args.rng)
@@ -118,18 +125,26 @@ def main():
     segments, samples, shadow = (float(x) for x in agg.tolist())
 
     if rank == 0:
-        # rank 0's own dominant kernel (k_bounce): algorithmic bytes = 128 B per ray segment it processed
-        # (64 B SoA path state read + written once per segment), time = HIP events recorded on
-        # the launch stream around the bounce-kernel loops inside rtw_render_device.
+        # Dominant kernel of rank 0 = the wavefront kernel with the largest summed device time. Its
+        # algorithmic bytes are 128 B per radiance segment it processed (64 B of SoA path state read
+        # and written once per segment; for k_trace, per ray pair traced); its time is measured live with HIP
+        # events recorded on the launch stream around every launch inside rtw_render_device.
+        names = ("k_first", "k_shade", "k_trace", "k_bounce")
+        k_s = [sum(s.kernel_seconds[i] for s in stats) for i in range(4)]
+        k_n = [sum(s.kernel_launches[i] for s in stats) for i in range(4)]
+        k_seg = [sum(s.kernel_segments[i] for s in stats) for i in range(4)]
+        dom = max(range(4), key=lambda i: k_s[i])
         seg0 = float(sum(s.segments for s in stats))
         b_s, b_n, r_s = (float(x) for x in kt.tolist())
-        achieved = 128.0 * seg0 / b_s / 1e9 if b_s > 0 else 0.0
+        dom_units = float(k_seg[dom]) if dom != 2 else float(k_seg[dom]) / 2.0
+        achieved = 128.0 * dom_units / k_s[dom] / 1e9 if k_s[dom] > 0 else 0.0
+        loop_achieved = 128.0 * seg0 / b_s / 1e9 if b_s > 0 else 0.0
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get("k_bounce_hbm_bytes_per_launch")
+                    traffic = json.load(f).get(names[dom] + "_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         line = {
@@ -149,12 +164,17 @@ def main():
                        "partition": f"{world} row tile(s) of {max_rows} rows, one RCCL gather per step" if world > 1 else "single tile",
                        "segments_per_sample": round(segments / samples, 4),
                        "shadow_rays_per_sample": round(shadow / samples, 4),
-                       "paths_in_flight": int(os.environ.get("RTW_POOL_PATHS", 1 << 26))},
+                       "paths_in_flight": int(os.environ.get("RTW_POOL_PATHS", 1 << 28))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "kernel": "k_bounce", "launches": int(b_n),
-                         "avg_launch_us": round(b_s / b_n * 1e6, 3) if b_n else None,
-                         "algorithmic_bytes_per_launch": round(128.0 * seg0 / b_n, 1) if b_n else None,
+                         "kernel": names[dom], "launches": int(k_n[dom]),
+                         "avg_launch_us": round(k_s[dom] / k_n[dom] * 1e6, 3) if k_n[dom] else None,
+                         "algorithmic_bytes_per_launch": round(128.0 * dom_units / k_n[dom], 1) if k_n[dom] else None,
+                         "whole_loop": {"achieved": round(loop_achieved, 2), "frac": round(loop_achieved / HBM_PEAK_GBS, 5),
+                                        "seconds": round(b_s, 4), "launches": int(b_n),
+                                        "note": "128 B x all segments / device time of the wavefront loops (all four kernels)"},
+                         "per_kernel": {names[i]: {"seconds": round(k_s[i], 4), "launches": int(k_n[i]), "units": int(k_seg[i])}
+                                        for i in range(4)},
                          "render_device_seconds_rank0": round(r_s, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:

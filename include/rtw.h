@@ -181,15 +181,22 @@ typedef struct rtw_params {
     int32_t reserved[2];
 } rtw_params;
 
+/* kernels of the wavefront loop, index into the per-kernel arrays of rtw_stats */
+enum { RTW_K_FIRST = 0, RTW_K_SHADE = 1, RTW_K_TRACE = 2, RTW_K_BOUNCE = 3, RTW_K_COUNT = 4 };
+
 typedef struct rtw_stats {
     uint64_t samples;           /* camera paths started                                              */
     uint64_t segments;          /* radiance ray segments traced (one optixTraverse of raygen.cu:41) */
     uint64_t shadow_rays;       /* occlusion probes traced (closehit.cu:95-101)                     */
     uint64_t algorithmic_bytes; /* 128*segments + 32*samples                 */
-    uint64_t bounce_launches;   /* launches of the dominant kernel                                  */
+    uint64_t bounce_launches;   /* launches of the wavefront-loop kernels (all four kinds)          */
     uint64_t reserved;
     double seconds;             /* device time of the whole render call (events on the stream)     */
-    double bounce_seconds;      /* device time inside the bounce-kernel loops only                 */
+    double bounce_seconds;      /* device time inside the wavefront loops (first launch to last)   */
+    /* per kernel kind, measured with HIP events recorded on the launch stream around every launch */
+    double kernel_seconds[RTW_K_COUNT];
+    uint64_t kernel_launches[RTW_K_COUNT];
+    uint64_t kernel_segments[RTW_K_COUNT]; /* radiance segments shaded by that kernel (k_trace: rays traced) */
 } rtw_stats;
 
 typedef struct rtw_ctx rtw_ctx;

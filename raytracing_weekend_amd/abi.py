@@ -78,7 +78,10 @@ class Params(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("bounce_launches", C.c_uint64), ("reserved", C.c_uint64),
-                ("seconds", C.c_double), ("bounce_seconds", C.c_double)]
+                ("seconds", C.c_double), ("bounce_seconds", C.c_double),
+                ("kernel_seconds", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_segments", C.c_uint64 * 4)]
+
+    KERNELS = ("k_first", "k_shade", "k_trace", "k_bounce")
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}

@@ -115,7 +115,7 @@ int ensure_pool(rtw_ctx* c, size_t paths, size_t npix, size_t cnt_words) {
         HIP_TRY(c, hipMalloc(&c->cnt, cnt_words * sizeof(uint32_t)));
         c->cnt_words = cnt_words;
     }
-    if (!c->d_stats) HIP_TRY(c, hipMalloc(&c->d_stats, 4 * sizeof(unsigned long long)));
+    if (!c->d_stats) HIP_TRY(c, hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)));
     return RTW_OK;
 }
 
@@ -125,10 +125,10 @@ size_t pool_target_paths() {
         long long v = atoll(e);
         if (v >= 1024) return (size_t)v;
     }
-    return (size_t)1 << 26;  // 67 M paths in flight: 9 GiB of ping-pong state + radiance slots (HBM-sized on purpose: long batches amortise the thin tail launches)
+    return (size_t)1 << 28;  // 67 M paths in flight: 9 GiB of ping-pong state + radiance slots (HBM-sized on purpose: long batches amortise the thin tail launches)
 }
 
-enum { LK_FIRST, LK_SHADE, LK_TRACE, LK_BOUNCE };
+enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE };
 void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s) {
     const bool lcg = rng_kind == RTW_RNG_TEA_LCG;
     switch (which) {
@@ -400,7 +400,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     std::vector<Step> sched;
     {
         const char* e = getenv("RTW_TAIL_START");
-        const int tail_start = (e && *e) ? std::max(1, atoi(e)) : 4;
+        const int tail_start = (e && *e) ? std::max(1, atoi(e)) : 6;
         const bool split = c->sc.n_vol == 0 && !(getenv("RTW_FUSED") && getenv("RTW_FUSED")[0] == '1');
         int d = 0, grp = 2, rep = 0;
         while (d < P->max_depth) {
@@ -430,10 +430,25 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     HIP_TRY(c, hipEventCreate(&ev_begin));
     HIP_TRY(c, hipEventCreate(&ev_end));
     std::vector<hipEvent_t> ev_loop;
+    std::vector<std::pair<int, hipEvent_t>> ev_k;  // (kernel kind, event) pairs: start, stop, start, stop ...
     auto cleanup = [&]() {
         (void)hipEventDestroy(ev_begin);
         (void)hipEventDestroy(ev_end);
         for (hipEvent_t e : ev_loop) (void)hipEventDestroy(e);
+        for (auto& e : ev_k) (void)hipEventDestroy(e.second);
+    };
+    auto timed_launch = [&](int kind, const KArgs& ka, int grid_, size_t lds_) -> hipError_t {
+        hipEvent_t a_ = nullptr, b_ = nullptr;
+        hipError_t er = hipEventCreate(&a_);
+        if (er != hipSuccess) return er;
+        ev_k.push_back({kind, a_});
+        er = hipEventCreate(&b_);
+        if (er != hipSuccess) return er;
+        ev_k.push_back({kind, b_});
+        er = hipEventRecord(a_, s);
+        if (er != hipSuccess) return er;
+        launch(kind, P->rng_kind, ka, grid_, lds_, s);
+        return hipEventRecord(b_, s);
     };
 #define HIP_TRY_C(expr)                                                               \
     do {                                                                              \
@@ -446,7 +461,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
 
     HIP_TRY_C(hipEventRecord(ev_begin, s));
     HIP_TRY_C(hipMemsetAsync(c->accum, 0, npix * sizeof(float4), s));
-    HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, 4 * sizeof(unsigned long long), s));
+    HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), s));
 
     const size_t lds = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
     uint64_t launches = 0;
@@ -487,7 +502,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             a.out = c->buf[0];
             a.cnt_out = c->cnt;
             a.depth = 0; a.n_iter = 1;
-            launch(LK_FIRST, P->rng_kind, a, grid, lds, s);
+            HIP_TRY_C(timed_launch(LK_FIRST, a, grid, lds));
             launches++;
             for (const Step& st : sched) {
                 a.in = c->buf[cur];
@@ -495,11 +510,11 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
                 a.depth = (uint32_t)st.depth;
                 a.n_iter = (uint32_t)st.n_iter;
                 if (st.kind == LK_TRACE) {
-                    launch(LK_TRACE, P->rng_kind, a, grid, lds, s);
+                    HIP_TRY_C(timed_launch(LK_TRACE, a, grid, lds));
                 } else {
                     a.out = c->buf[cur ^ 1];
                     a.cnt_out = c->cnt + (ci + 1) * regions;
-                    launch(st.kind, P->rng_kind, a, grid, st.kind == LK_BOUNCE ? lds : 0, s);
+                    HIP_TRY_C(timed_launch(st.kind, a, grid, st.kind == LK_BOUNCE ? lds : 0));
                     cur ^= 1;
                     ci++;
                 }
@@ -516,7 +531,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     HIP_TRY_C(hipEventRecord(ev_end, s));
     HIP_TRY_C(hipEventSynchronize(ev_end));
 
-    unsigned long long hs[4] = {0, 0, 0, 0};
+    unsigned long long hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY_C(hipMemcpy(hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost));
     if (stats) {
         float ms = 0.f;
@@ -529,6 +544,13 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             loop_ms += m;
         }
         stats->bounce_seconds = loop_ms * 1e-3;
+        for (size_t i = 0; i + 1 < ev_k.size(); i += 2) {
+            float m = 0.f;
+            HIP_TRY_C(hipEventElapsedTime(&m, ev_k[i].second, ev_k[i + 1].second));
+            stats->kernel_seconds[ev_k[i].first] += (double)m * 1e-3;
+            stats->kernel_launches[ev_k[i].first]++;
+        }
+        for (int k = 0; k < RTW_K_COUNT; k++) stats->kernel_segments[k] = hs[2 + k];
         stats->bounce_launches = launches;
         stats->samples = (uint64_t)npix * (uint64_t)P->spp;
         stats->segments = hs[0];

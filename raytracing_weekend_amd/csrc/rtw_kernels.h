@@ -46,7 +46,7 @@ struct KArgs {
     float4* lbuf;               // per path id: final radiance of the sample
     const uint32_t* cnt_in;     // live paths per region (input)
     uint32_t* cnt_out;          // live paths per region (output), zeroed per batch
-    unsigned long long* stats;  // [0] segments, [1] shadow probes
+    unsigned long long* stats;  // [0] segments, [1] shadow probes, [2 + kind] segments per kernel kind
     uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, trace_first;
 };
 
@@ -364,7 +364,7 @@ RTW_DEV void compact_store(const KArgs& A, uint32_t region, bool keep, const Pat
     base = __builtin_amdgcn_readfirstlane(base);
     if (keep) store_path(A.out, (size_t)region * A.region_cap + base + before, p);
 }
-RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow) {
+RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow, int kind) {
     for (int off = 32; off > 0; off >>= 1) {
         n_seg += __shfl_down(n_seg, off);
         n_shadow += __shfl_down(n_shadow, off);
@@ -372,6 +372,7 @@ RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow) {
     if ((threadIdx.x & 63u) == 0 && (n_seg | n_shadow)) {
         atomicAdd(&A.stats[0], (unsigned long long)n_seg);
         atomicAdd(&A.stats[1], (unsigned long long)n_shadow);
+        atomicAdd(&A.stats[2 + kind], (unsigned long long)n_seg);
     }
 }
 
@@ -473,7 +474,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
         }
         compact_store(A, path_region, keep, p);
     }
-    flush_stats(A, n_seg, n_shadow);
+    flush_stats(A, n_seg, n_shadow, RTW_K_FIRST);
 }
 
 // ------------------------------------------------------------------ k_trace
@@ -482,6 +483,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED
     const uint32_t tid = threadIdx.x;
+    uint32_t n_rays = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
     for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
         uint32_t region, chunk, n_in;
@@ -495,17 +497,22 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(const KArgs A) {
         const float gt = gather_time_of(A, p.gk);
         float th = 0.f;
         int prim = -1;
-        if (!(p.gk & kZombie))
+        if (!(p.gk & kZombie)) {
             traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, s_stack + tid, A.stack_stride, th, prim);
+            n_rays++;
+        }
         uint32_t occl = 0;
         if (p.ltmax >= 0.0f) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
             float st;
             int sprim;
             traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, s_stack + tid, A.stack_stride, st, sprim);
             occl = sprim >= 0 ? 0x80000000u : 0u;
+            n_rays++;
         }
         A.hit[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
     }
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
 
 // ------------------------------------------------------------------ k_shade
@@ -562,7 +569,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_shade(const KArgs A) 
         }
         compact_store(A, region, keep, p);
     }
-    flush_stats(A, n_seg, n_shadow);
+    flush_stats(A, n_seg, n_shadow, RTW_K_SHADE);
 }
 
 // ------------------------------------------------------------------ k_bounce (fused)
@@ -628,7 +635,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
         }
         compact_store(A, region, keep, p);
     }
-    flush_stats(A, n_seg, n_shadow);
+    flush_stats(A, n_seg, n_shadow, RTW_K_BOUNCE);
 }
 
 // sums the S sample slots of every pixel in ascending sample order (fixed order => reproducible bits)

@@ -16,7 +16,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def test_struct_sizes_match_header():
     assert C.sizeof(abi.Prim) == 64 and C.sizeof(abi.Xform) == 96 and C.sizeof(abi.Material) == 16
     assert C.sizeof(abi.Texture) == 32 and C.sizeof(abi.Light) == 64 and C.sizeof(abi.Pdf) == 48
-    assert C.sizeof(abi.Camera) == 96 and C.sizeof(abi.Params) == 48 and C.sizeof(abi.Stats) == 64
+    assert C.sizeof(abi.Camera) == 96 and C.sizeof(abi.Params) == 48 and C.sizeof(abi.Stats) == 160
 
 
 def test_cornell_box_blob():
