@@ -48,7 +48,7 @@ struct rtw_ctx {
     // render pool
     size_t pool_paths = 0;
     PathBuf buf[2] = {};
-    uint2* hit = nullptr;
+    uint2* hit[2] = {nullptr, nullptr};
     float4* lbuf = nullptr;
     float4* accum = nullptr;
     size_t accum_pix = 0;
@@ -81,8 +81,7 @@ void free_pool(rtw_ctx* c) {
         for (void* q : pl) if (q) (void)hipFree(q);
         c->buf[b] = PathBuf{};
     }
-    if (c->hit) (void)hipFree(c->hit);
-    c->hit = nullptr;
+    for (int b = 0; b < 2; b++) { if (c->hit[b]) (void)hipFree(c->hit[b]); c->hit[b] = nullptr; }
     if (c->lbuf) (void)hipFree(c->lbuf);
     c->lbuf = nullptr;
     c->pool_paths = 0;
@@ -99,7 +98,7 @@ int ensure_pool(rtw_ctx* c, size_t paths, size_t npix, size_t cnt_words) {
             HIP_TRY(c, hipMalloc(&c->buf[b].p4, paths * sizeof(float4)));
             HIP_TRY(c, hipMalloc(&c->buf[b].p5, paths * sizeof(uint4)));
         }
-        HIP_TRY(c, hipMalloc(&c->hit, paths * sizeof(uint2)));
+        for (int b = 0; b < 2; b++) HIP_TRY(c, hipMalloc(&c->hit[b], paths * sizeof(uint2)));
         HIP_TRY(c, hipMalloc(&c->lbuf, paths * sizeof(float4)));
         c->pool_paths = paths;
     }
@@ -137,8 +136,8 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
         else hipLaunchKernelGGL((k_first<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
     case LK_SHADE:
-        if (lcg) hipLaunchKernelGGL((k_shade<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((k_shade<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), 0, s, a);
+        if (lcg) hipLaunchKernelGGL((k_shade<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_shade<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
     case LK_TRACE:
         hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), lds, s, a);
@@ -392,7 +391,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     // region capacity: a multiple of 256 paths, at least 16384, large enough that <= kMaxRegions regions cover the pool
     size_t region_cap = std::max<size_t>(kMinRegionCap, (((paths_max + kMaxRegions - 1) / kMaxRegions) + kBlock - 1) / kBlock * kBlock);
     const uint32_t regions_max = (uint32_t)((paths_max + region_cap - 1) / region_cap);
-    bool split_first = false;
+    bool split_first = false, fuse_trace = false;
     // Launch schedule of one batch. Wide bounces: one k_shade + one k_trace per bounce (split pipeline; scenes
     // whose intersection programs draw random numbers keep trace and shade fused in k_bounce instead).
     // Thin tail: k_bounce with several bounces in registers, in growing groups.
@@ -402,12 +401,13 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         const char* e = getenv("RTW_TAIL_START");
         const int tail_start = (e && *e) ? std::max(1, atoi(e)) : 6;
         const bool split = c->sc.n_vol == 0 && !(getenv("RTW_FUSED") && getenv("RTW_FUSED")[0] == '1');
+        fuse_trace = split && getenv("RTW_FUSE_TRACE") && getenv("RTW_FUSE_TRACE")[0] == '1';
         int d = 0, grp = 2, rep = 0;
         while (d < P->max_depth) {
             if (d < tail_start) {
                 if (split) {
                     // k_first has already traced and shaded depth 0
-                    if (d > 0) { sched.push_back({LK_TRACE, d, 1}); sched.push_back({LK_SHADE, d, 1}); }
+                    if (d > 0) { if (!fuse_trace) sched.push_back({LK_TRACE, d, 1}); sched.push_back({LK_SHADE, d, 1}); }
                 } else {
                     sched.push_back({LK_BOUNCE, d, 1});
                 }
@@ -473,7 +473,6 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             HIP_TRY_C(hipMemsetAsync(c->cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), s));
             KArgs a{};
             a.sc = c->sc;
-            a.hit = c->hit;
             a.lbuf = c->lbuf;
             a.stats = c->d_stats;
             a.n_regions = regions;
@@ -487,7 +486,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             a.max_depth = (uint32_t)P->max_depth;
             a.stack_stride = kBlock;
             a.region_cap = (uint32_t)region_cap;
-            a.trace_first = split_first ? 1u : 0u;
+            a.trace_first = (split_first ? 1u : 0u) | (fuse_trace ? 2u : 0u);
             const uint32_t n_chunks = (uint32_t)((paths + kBlock - 1) / kBlock);
             const int grid = (int)std::min<uint32_t>(n_chunks, (uint32_t)c->n_cu * 8u);
             hipEvent_t e0 = nullptr, e1 = nullptr;
@@ -500,12 +499,15 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             int cur = 0;
             size_t ci = 0;  // index of the region-counter row describing buffer `cur`
             a.out = c->buf[0];
+            a.hit_out = c->hit[0];
             a.cnt_out = c->cnt;
             a.depth = 0; a.n_iter = 1;
             HIP_TRY_C(timed_launch(LK_FIRST, a, grid, lds));
             launches++;
             for (const Step& st : sched) {
                 a.in = c->buf[cur];
+                a.hit = c->hit[cur];
+                a.hit_out = c->hit[cur];  // k_trace fills the records of the buffer it reads
                 a.cnt_in = c->cnt + ci * regions;
                 a.depth = (uint32_t)st.depth;
                 a.n_iter = (uint32_t)st.n_iter;
@@ -513,8 +515,12 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
                     HIP_TRY_C(timed_launch(LK_TRACE, a, grid, lds));
                 } else {
                     a.out = c->buf[cur ^ 1];
+                    a.hit_out = c->hit[cur ^ 1];
                     a.cnt_out = c->cnt + (ci + 1) * regions;
-                    HIP_TRY_C(timed_launch(st.kind, a, grid, st.kind == LK_BOUNCE ? lds : 0));
+                    // with the trace fused in, the last k_shade before the tail leaves its probes to k_bounce
+                    KArgs b = a;
+                    if (fuse_trace && st.kind == LK_SHADE && (&st == &sched.back() || (&st)[1].kind != LK_SHADE)) b.trace_first &= ~2u;
+                    HIP_TRY_C(timed_launch(st.kind, b, grid, lds));
                     cur ^= 1;
                     ci++;
                 }

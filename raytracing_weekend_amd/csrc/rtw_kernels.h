@@ -42,7 +42,8 @@ struct PathBuf {
 struct KArgs {
     DScene sc;
     PathBuf in, out;
-    uint2* hit;                 // per input slot: t, (prim+1) | occluded<<31
+    const uint2* hit;           // per input slot: t, (prim+1) | occluded<<31
+    uint2* hit_out;             // hit records of the OUTPUT slots (k_trace: of the slots it reads)
     float4* lbuf;               // per path id: final radiance of the sample
     const uint32_t* cnt_in;     // live paths per region (input)
     uint32_t* cnt_out;          // live paths per region (output), zeroed per batch
@@ -135,6 +136,12 @@ RTW_DEV void worklist_lookup(const WorkList& w, uint32_t n_regions, uint32_t vc,
     chunk = vc - w.pref[lo];
     n_in = w.raw[lo];
 }
+
+struct NoRng {
+    uint32_t a, b;
+    RTW_DEV float next1() { return 0.5f; }
+    RTW_DEV float randf1() { return 0.5f; }
+};
 
 // ------------------------------------------------------------------ shading
 struct Nee {
@@ -355,14 +362,37 @@ RTW_DEV void finish_path(const KArgs& A, uint32_t path_id, v3 L) {
     A.lbuf[path_id] = make_float4(lx, ly, lz, 0.f);
 }
 // wave64 ballot + popcount prefix; one atomic per wave reserves its slice of the region's output
-RTW_DEV void compact_store(const KArgs& A, uint32_t region, bool keep, const Path& p) {
+RTW_DEV size_t compact_store(const KArgs& A, uint32_t region, bool keep, const Path& p) {
     const unsigned long long ballot = __ballot(keep);
-    if (!ballot) return;
+    if (!ballot) return 0;
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
     uint32_t base = 0;
     if ((threadIdx.x & 63u) == 0) base = atomicAdd(&A.cnt_out[region], (uint32_t)__popcll(ballot));
     base = __builtin_amdgcn_readfirstlane(base);
-    if (keep) store_path(A.out, (size_t)region * A.region_cap + base + before, p);
+    const size_t slot = (size_t)region * A.region_cap + base + before;
+    if (keep) store_path(A.out, slot, p);
+    return slot;
+}
+// The trace pass of one path (what k_trace does per lane), callable from a shading kernel right after it has
+// stored the path: radiance ray closest hit + queued shadow probe any-hit, result into the hit buffer.
+RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, uint32_t* stack, uint32_t& n_rays) {
+    NoRng ng;
+    const float gt = gather_time_of(A, p.gk);
+    float th = 0.f;
+    int prim = -1;
+    if (!(p.gk & kZombie)) {
+        traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, stack, A.stack_stride, th, prim);
+        n_rays++;
+    }
+    uint32_t occl = 0;
+    if (p.ltmax >= 0.0f) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
+        float st;
+        int sprim;
+        traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, stack, A.stack_stride, st, sprim);
+        occl = sprim >= 0 ? 0x80000000u : 0u;
+        n_rays++;
+    }
+    A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
 }
 RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow, int kind) {
     for (int off = 32; off > 0; off >>= 1) {
@@ -376,18 +406,12 @@ RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow, int 
     }
 }
 
-struct NoRng {
-    uint32_t a, b;
-    RTW_DEV float next1() { return 0.5f; }
-    RTW_DEV float randf1() { return 0.5f; }
-};
-
 // ------------------------------------------------------------------ k_first
 template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
-    uint32_t n_seg = 0, n_shadow = 0;
+    uint32_t n_seg = 0, n_shadow = 0, n_rays = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
     for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
         const uint32_t path_id = vc * kBlock + tid;
@@ -442,7 +466,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
         p.T = V(1.f, 1.f, 1.f); p.L = V(0.f, 0.f, 0.f); p.c = V(0.f, 0.f, 0.f);
         p.a = g.a; p.b = g.b;
         keep = true;
-        if (A.trace_first) {
+        if (A.trace_first & 1u) {
             // split pipeline: trace and shade the primary segment here (primary rays are coherent, so the fused
             // form costs no divergence and saves writing and re-reading 104 B per camera path, half of which
             // leave the scene at once in a 16:9 Cornell frame)
@@ -472,9 +496,12 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             }
         }
         }
-        compact_store(A, path_region, keep, p);
+        const size_t oslot = compact_store(A, path_region, keep, p);
+        if ((A.trace_first & 2u) && keep) trace_path(A, p, oslot, s_stack + tid, n_rays);
     }
     flush_stats(A, n_seg, n_shadow, RTW_K_FIRST);
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
 
 // ------------------------------------------------------------------ k_trace
@@ -493,23 +520,7 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(const KArgs A) {
         const size_t slot = (size_t)region * A.region_cap + idx;
         Path p;
         load_trace_part(A.in, slot, p);
-        NoRng ng;
-        const float gt = gather_time_of(A, p.gk);
-        float th = 0.f;
-        int prim = -1;
-        if (!(p.gk & kZombie)) {
-            traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, s_stack + tid, A.stack_stride, th, prim);
-            n_rays++;
-        }
-        uint32_t occl = 0;
-        if (p.ltmax >= 0.0f) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
-            float st;
-            int sprim;
-            traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, s_stack + tid, A.stack_stride, st, sprim);
-            occl = sprim >= 0 ? 0x80000000u : 0u;
-            n_rays++;
-        }
-        A.hit[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
+        trace_path(A, p, slot, s_stack + tid, n_rays);
     }
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
@@ -518,9 +529,10 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(const KArgs A) {
 // ------------------------------------------------------------------ k_shade
 template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_shade(const KArgs A) {
+    extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED
     const uint32_t tid = threadIdx.x;
-    uint32_t n_seg = 0, n_shadow = 0;
+    uint32_t n_seg = 0, n_shadow = 0, n_rays = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
     for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
         uint32_t region, chunk, n_in;
@@ -567,9 +579,12 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_shade(const KArgs A) 
                 }
             }
         }
-        compact_store(A, region, keep, p);
+        const size_t oslot = compact_store(A, region, keep, p);
+        if ((A.trace_first & 2u) && keep) trace_path(A, p, oslot, s_stack + tid, n_rays);
     }
     flush_stats(A, n_seg, n_shadow, RTW_K_SHADE);
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
 
 // ------------------------------------------------------------------ k_bounce (fused)
