@@ -46,14 +46,20 @@ struct rtw_ctx {
     void* d_scene = nullptr;   // one allocation holding all scene tables
     int stack_depth = 0;
     // render pool
-    size_t pool_paths = 0;
-    PathBuf buf[2] = {};
-    uint2* hit[2] = {nullptr, nullptr};
-    float4* lbuf = nullptr;
+    // Two independent "lanes" (stream + path pool): consecutive batches alternate between them so that the
+    // bandwidth-bound kernels of one batch overlap the compute- and latency-bound kernels of the other.
+    struct Lane {
+        hipStream_t st = nullptr;
+        hipEvent_t ev_done = nullptr, ev_free = nullptr;
+        PathBuf buf[2] = {};
+        uint2* hit[2] = {nullptr, nullptr};
+        float4* lbuf = nullptr;
+        uint32_t* cnt = nullptr;
+        size_t cnt_words = 0;
+        size_t paths = 0;
+    } lane[4];
     float4* accum = nullptr;
     size_t accum_pix = 0;
-    uint32_t* cnt = nullptr;
-    size_t cnt_words = 0;
     unsigned long long* d_stats = nullptr;
     float4* d_out = nullptr;
     size_t out_pix = 0;
@@ -75,44 +81,65 @@ int fail(rtw_ctx* c, int code, const std::string& msg) {
                         std::string(#expr) + ": " + hipGetErrorString(e_));                        \
     } while (0)
 
-void free_pool(rtw_ctx* c) {
+void free_lane(rtw_ctx::Lane& L) {
     for (int b = 0; b < 2; b++) {
-        void* pl[6] = {c->buf[b].p0, c->buf[b].p1, c->buf[b].p2, c->buf[b].p3, c->buf[b].p4, c->buf[b].p5};
+        void* pl[6] = {L.buf[b].p0, L.buf[b].p1, L.buf[b].p2, L.buf[b].p3, L.buf[b].p4, L.buf[b].p5};
         for (void* q : pl) if (q) (void)hipFree(q);
-        c->buf[b] = PathBuf{};
+        L.buf[b] = PathBuf{};
+        if (L.hit[b]) (void)hipFree(L.hit[b]);
+        L.hit[b] = nullptr;
     }
-    for (int b = 0; b < 2; b++) { if (c->hit[b]) (void)hipFree(c->hit[b]); c->hit[b] = nullptr; }
-    if (c->lbuf) (void)hipFree(c->lbuf);
-    c->lbuf = nullptr;
-    c->pool_paths = 0;
+    if (L.lbuf) (void)hipFree(L.lbuf);
+    L.lbuf = nullptr;
+    L.paths = 0;
+}
+void free_pool(rtw_ctx* c) {
+    for (auto& L : c->lane) {
+        free_lane(L);
+        if (L.cnt) (void)hipFree(L.cnt);
+        L.cnt = nullptr; L.cnt_words = 0;
+    }
 }
 
-int ensure_pool(rtw_ctx* c, size_t paths, size_t npix, size_t cnt_words) {
-    if (paths > c->pool_paths) {
-        free_pool(c);
+int ensure_lane(rtw_ctx* c, rtw_ctx::Lane& L, size_t paths, size_t cnt_words) {
+    if (!L.st) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        HIP_TRY(c, hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&L.ev_free, hipEventDisableTiming));
+    }
+    if (paths > L.paths) {
+        free_lane(L);
         for (int b = 0; b < 2; b++) {
-            HIP_TRY(c, hipMalloc(&c->buf[b].p0, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&c->buf[b].p1, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&c->buf[b].p2, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&c->buf[b].p3, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&c->buf[b].p4, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&c->buf[b].p5, paths * sizeof(uint4)));
+            HIP_TRY(c, hipMalloc(&L.buf[b].p0, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&L.buf[b].p1, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&L.buf[b].p2, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&L.buf[b].p3, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&L.buf[b].p4, paths * sizeof(float4)));
+            HIP_TRY(c, hipMalloc(&L.buf[b].p5, paths * sizeof(uint4)));
+            HIP_TRY(c, hipMalloc(&L.hit[b], paths * sizeof(uint2)));
         }
-        for (int b = 0; b < 2; b++) HIP_TRY(c, hipMalloc(&c->hit[b], paths * sizeof(uint2)));
-        HIP_TRY(c, hipMalloc(&c->lbuf, paths * sizeof(float4)));
-        c->pool_paths = paths;
+        HIP_TRY(c, hipMalloc(&L.lbuf, paths * sizeof(float4)));
+        L.paths = paths;
+    }
+    if (cnt_words > L.cnt_words) {
+        if (L.cnt) (void)hipFree(L.cnt);
+        L.cnt = nullptr; L.cnt_words = 0;
+        HIP_TRY(c, hipMalloc(&L.cnt, cnt_words * sizeof(uint32_t)));
+        L.cnt_words = cnt_words;
+    }
+    return RTW_OK;
+}
+
+int ensure_pool(rtw_ctx* c, int n_lanes, size_t paths, size_t npix, size_t cnt_words) {
+    for (int l = 0; l < n_lanes; l++) {
+        int rc = ensure_lane(c, c->lane[l], paths, cnt_words);
+        if (rc) return rc;
     }
     if (npix > c->accum_pix) {
         if (c->accum) (void)hipFree(c->accum);
         c->accum = nullptr; c->accum_pix = 0;
         HIP_TRY(c, hipMalloc(&c->accum, npix * sizeof(float4)));
         c->accum_pix = npix;
-    }
-    if (cnt_words > c->cnt_words) {
-        if (c->cnt) (void)hipFree(c->cnt);
-        c->cnt = nullptr; c->cnt_words = 0;
-        HIP_TRY(c, hipMalloc(&c->cnt, cnt_words * sizeof(uint32_t)));
-        c->cnt_words = cnt_words;
     }
     if (!c->d_stats) HIP_TRY(c, hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)));
     return RTW_OK;
@@ -181,8 +208,12 @@ int rtw_destroy(rtw_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_pool(c);
+    for (auto& L : c->lane) {
+        if (L.ev_done) (void)hipEventDestroy(L.ev_done);
+        if (L.ev_free) (void)hipEventDestroy(L.ev_free);
+        if (L.st) (void)hipStreamDestroy(L.st);
+    }
     if (c->accum) (void)hipFree(c->accum);
-    if (c->cnt) (void)hipFree(c->cnt);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_scene) (void)hipFree(c->d_scene);
@@ -383,8 +414,11 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     if (npix == 0) return RTW_OK;
     if (npix > 0xffffffffull / 2) return fail(c, RTW_ERR_UNSUPPORTED, "tile too large");
 
-    // samples per pass: keep about pool_target paths in flight
-    size_t S = P->samples_per_pass > 0 ? (size_t)P->samples_per_pass : std::max<size_t>(1, pool_target_paths() / npix);
+    // samples per pass: keep about pool_target paths in flight, split over the lanes
+    int want_lanes = 2;
+    if (const char* e = getenv("RTW_LANES")) want_lanes = std::max(1, std::min(4, atoi(e)));
+    size_t S = P->samples_per_pass > 0 ? (size_t)P->samples_per_pass
+                                       : std::max<size_t>(1, pool_target_paths() / (size_t)want_lanes / npix);
     S = std::min<size_t>(S, (size_t)P->spp);
     while (S > 1 && npix * S > 0xfffffff0ull) S--;
     const size_t paths_max = npix * S;
@@ -424,7 +458,9 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         split_first = split;
     }
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
-    int rc = ensure_pool(c, (size_t)regions_max * region_cap, npix, cnt_words);
+    const size_t n_batches = ((size_t)P->spp + S - 1) / S;
+    const int n_lanes = (int)std::min<size_t>((size_t)want_lanes, std::max<size_t>(n_batches, 1));
+    int rc = ensure_pool(c, n_lanes, (size_t)regions_max * region_cap, npix, cnt_words);
     if (rc) return rc;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     HIP_TRY(c, hipEventCreate(&ev_begin));
@@ -437,7 +473,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         for (hipEvent_t e : ev_loop) (void)hipEventDestroy(e);
         for (auto& e : ev_k) (void)hipEventDestroy(e.second);
     };
-    auto timed_launch = [&](int kind, const KArgs& ka, int grid_, size_t lds_) -> hipError_t {
+    auto timed_launch = [&](hipStream_t ls, int kind, const KArgs& ka, int grid_, size_t lds_) -> hipError_t {
         hipEvent_t a_ = nullptr, b_ = nullptr;
         hipError_t er = hipEventCreate(&a_);
         if (er != hipSuccess) return er;
@@ -445,10 +481,10 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         er = hipEventCreate(&b_);
         if (er != hipSuccess) return er;
         ev_k.push_back({kind, b_});
-        er = hipEventRecord(a_, s);
+        er = hipEventRecord(a_, ls);
         if (er != hipSuccess) return er;
-        launch(kind, P->rng_kind, ka, grid_, lds_, s);
-        return hipEventRecord(b_, s);
+        launch(kind, P->rng_kind, ka, grid_, lds_, ls);
+        return hipEventRecord(b_, ls);
     };
 #define HIP_TRY_C(expr)                                                               \
     do {                                                                              \
@@ -466,14 +502,24 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     const size_t lds = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
     uint64_t launches = 0;
     if (P->max_depth > 0) {
-        for (size_t s0 = 0; s0 < (size_t)P->spp; s0 += S) {
+        // the lanes start once the accumulators are cleared
+        hipEvent_t ev_ready = nullptr;
+        HIP_TRY_C(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
+        ev_loop.push_back(ev_ready);
+        HIP_TRY_C(hipEventRecord(ev_ready, s));
+        size_t bi = 0;
+        for (size_t s0 = 0; s0 < (size_t)P->spp; s0 += S, bi++) {
+            rtw_ctx::Lane& L = c->lane[bi % (size_t)n_lanes];
+            hipStream_t ls = L.st;
             const size_t Sb = std::min(S, (size_t)P->spp - s0);
             const size_t paths = npix * Sb;
             const uint32_t regions = (uint32_t)((paths + region_cap - 1) / region_cap);
-            HIP_TRY_C(hipMemsetAsync(c->cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), s));
+            // this lane's pool is free again once the resolve of its previous batch has run on the main stream
+            HIP_TRY_C(hipStreamWaitEvent(ls, bi < (size_t)n_lanes ? ev_ready : L.ev_free, 0));
+            HIP_TRY_C(hipMemsetAsync(L.cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), ls));
             KArgs a{};
             a.sc = c->sc;
-            a.lbuf = c->lbuf;
+            a.lbuf = L.lbuf;
             a.stats = c->d_stats;
             a.n_regions = regions;
             a.n_paths = (uint32_t)paths;
@@ -488,47 +534,48 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             a.region_cap = (uint32_t)region_cap;
             a.trace_first = (split_first ? 1u : 0u) | (fuse_trace ? 2u : 0u);
             const uint32_t n_chunks = (uint32_t)((paths + kBlock - 1) / kBlock);
-            const int grid = (int)std::min<uint32_t>(n_chunks, (uint32_t)c->n_cu * 8u);
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            HIP_TRY_C(hipEventCreate(&e0));
-            ev_loop.push_back(e0);
-            HIP_TRY_C(hipEventCreate(&e1));
-            ev_loop.push_back(e1);
-            HIP_TRY_C(hipEventRecord(e0, s));
+            // persistent grids: 8 workgroups per CU when a lane has the GPU to itself, 4 when two lanes share it
+            uint32_t grid_mult = n_lanes > 1 ? 4u : 8u;
+            if (const char* e = getenv("RTW_GRID_MULT")) grid_mult = (uint32_t)std::max(1, atoi(e));
+            const int grid = (int)std::min<uint32_t>(n_chunks, (uint32_t)c->n_cu * grid_mult);
             // k_first fills buffer 0 (and the hit buffer); every compacting launch then flips the buffers
             int cur = 0;
             size_t ci = 0;  // index of the region-counter row describing buffer `cur`
-            a.out = c->buf[0];
-            a.hit_out = c->hit[0];
-            a.cnt_out = c->cnt;
+            a.out = L.buf[0];
+            a.hit_out = L.hit[0];
+            a.cnt_out = L.cnt;
             a.depth = 0; a.n_iter = 1;
-            HIP_TRY_C(timed_launch(LK_FIRST, a, grid, lds));
+            HIP_TRY_C(timed_launch(ls, LK_FIRST, a, grid, lds));
             launches++;
-            for (const Step& st : sched) {
-                a.in = c->buf[cur];
-                a.hit = c->hit[cur];
-                a.hit_out = c->hit[cur];  // k_trace fills the records of the buffer it reads
-                a.cnt_in = c->cnt + ci * regions;
+            for (size_t si = 0; si < sched.size(); si++) {
+                const Step& st = sched[si];
+                a.in = L.buf[cur];
+                a.hit = L.hit[cur];
+                a.hit_out = L.hit[cur];  // k_trace fills the records of the buffer it reads
+                a.cnt_in = L.cnt + ci * regions;
                 a.depth = (uint32_t)st.depth;
                 a.n_iter = (uint32_t)st.n_iter;
                 if (st.kind == LK_TRACE) {
-                    HIP_TRY_C(timed_launch(LK_TRACE, a, grid, lds));
+                    HIP_TRY_C(timed_launch(ls, LK_TRACE, a, grid, lds));
                 } else {
-                    a.out = c->buf[cur ^ 1];
-                    a.hit_out = c->hit[cur ^ 1];
-                    a.cnt_out = c->cnt + (ci + 1) * regions;
+                    a.out = L.buf[cur ^ 1];
+                    a.hit_out = L.hit[cur ^ 1];
+                    a.cnt_out = L.cnt + (ci + 1) * regions;
                     // with the trace fused in, the last k_shade before the tail leaves its probes to k_bounce
                     KArgs b = a;
-                    if (fuse_trace && st.kind == LK_SHADE && (&st == &sched.back() || (&st)[1].kind != LK_SHADE)) b.trace_first &= ~2u;
-                    HIP_TRY_C(timed_launch(st.kind, b, grid, lds));
+                    if (fuse_trace && st.kind == LK_SHADE && (si + 1 == sched.size() || sched[si + 1].kind != LK_SHADE)) b.trace_first &= ~2u;
+                    HIP_TRY_C(timed_launch(ls, st.kind, b, grid, lds));
                     cur ^= 1;
                     ci++;
                 }
                 launches++;
             }
-            HIP_TRY_C(hipEventRecord(e1, s));
+            HIP_TRY_C(hipEventRecord(L.ev_done, ls));
+            // batches are resolved into the accumulators in order, on the main stream
+            HIP_TRY_C(hipStreamWaitEvent(s, L.ev_done, 0));
             hipLaunchKernelGGL(k_resolve, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, (size_t)c->n_cu * 8)), dim3(kBlock), 0, s,
-                               (const float4*)c->lbuf, c->accum, (uint32_t)npix, (uint32_t)Sb);
+                               (const float4*)L.lbuf, c->accum, (uint32_t)npix, (uint32_t)Sb);
+            HIP_TRY_C(hipEventRecord(L.ev_free, s));
         }
     }
     hipLaunchKernelGGL(k_finish, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, (size_t)c->n_cu * 8)), dim3(kBlock), 0, s,
@@ -543,13 +590,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         float ms = 0.f;
         HIP_TRY_C(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->seconds = (double)ms * 1e-3;
-        double loop_ms = 0.0;
-        for (size_t i = 0; i + 1 < ev_loop.size(); i += 2) {
-            float m = 0.f;
-            HIP_TRY_C(hipEventElapsedTime(&m, ev_loop[i], ev_loop[i + 1]));
-            loop_ms += m;
-        }
-        stats->bounce_seconds = loop_ms * 1e-3;
+        stats->bounce_seconds = stats->seconds;  // the lanes overlap: the loop time is the elapsed time of the call
         for (size_t i = 0; i + 1 < ev_k.size(); i += 2) {
             float m = 0.f;
             HIP_TRY_C(hipEventElapsedTime(&m, ev_k[i].second, ev_k[i + 1].second));
