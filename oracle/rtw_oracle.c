@@ -187,6 +187,7 @@ typedef struct {
     uint32_t lcg[3];
     uint32_t key0, pixel, sample;
     uint32_t draw[3];
+    uint32_t seg_base; /* Philox stream 1: draw counter at the start of the current closest-hit program */
 } rng_t;
 
 static float rng_next(rng_t* g, int stream) {
@@ -197,6 +198,21 @@ static float rng_next(rng_t* g, int stream) {
     uint32_t out[4];
     rtwo_philox4x32_10(ctr, key, out);
     return (float)(out[d & 3u] >> 8) * (1.0f / 16777216.0f);
+}
+/* The Russian-roulette draw (raygen.cu:77). TEA+LCG: the next value of prd.seed, as in the reference.
+ * Philox: a fifth uniform cut from the low bytes of words 0..2 of the block the segment used last (its four
+ * 24-bit uniforms use the high bytes), so that a Lambertian segment (2 scatter + 2 light + 1 roulette draws)
+ * costs one Philox block instead of two. The draw counter does not move. */
+static float rng_rr(rng_t* g) {
+    if (g->kind == RTW_RNG_TEA_LCG) return rtwo_lcg_rnd(&g->lcg[1]);
+    uint32_t a = g->draw[1];
+    uint32_t blk = (a == g->seg_base) ? (a >> 2) : ((a - 1u) >> 2);
+    uint32_t ctr[4] = {g->pixel, g->sample, blk, 1u};
+    uint32_t key[2] = {g->key0, 0u};
+    uint32_t out[4];
+    rtwo_philox4x32_10(ctr, key, out);
+    uint32_t v = ((out[0] & 0xffu) << 16) | ((out[1] & 0xffu) << 8) | (out[2] & 0xffu);
+    return (float)v * (1.0f / 16777216.0f);
 }
 /* randf(thePrd->seed) of geometry/volumeBox.cu:79: xorshift on the SAME prd.seed word */
 static float rng_randf(rng_t* g) {
@@ -532,6 +548,9 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
             ev = EV_MISS;
         } else {
             /* shaders/closehit.cu:45-121 */
+            /* Philox stream 1: the closest-hit program of every segment starts at a fresh 4-word block, so that all
+             * lanes of a GPU wave refill their generator at the same call sites (unused words are skipped) */
+            if (g.kind == RTW_RNG_PHILOX) { g.draw[1] = (g.draw[1] + 3u) & ~3u; g.seg_base = g.draw[1]; }
             v3 hp, hn;
             hit_attributes(sc, &h, origin, dir, &hp, &hn);
             const rtw_material* m = &sc->mats[sc->prims[h.prim].material];
@@ -693,7 +712,7 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
         if (2 <= depth) {
             /* raygen.cu:74-82 */
             float p = fmaxf(fmaxf(T.x, T.y), T.z);
-            if (p < rng_next(&g, 1)) break;
+            if (p < rng_rr(&g)) break;
             T = vscale(T, 1.0f / p);
         }
         depth++;

@@ -156,16 +156,18 @@ struct Rng<RTW_RNG_TEA_LCG> {
     RTW_DEV void init(uint32_t, uint32_t, uint32_t, uint32_t wa, uint32_t wb) { a = wa; b = wb; }
     RTW_DEV float next1() { return lcg_rnd(a); }
     RTW_DEV float randf1() { return xorshift_randf(a); }
+    RTW_DEV void align_block() {}
+    RTW_DEV float rr_draw() { return lcg_rnd(a); }  // raygen.cu:77
     RTW_DEV float ray_time(uint32_t) { return lcg_rnd(b); }
 };
 
 template <>
 struct Rng<RTW_RNG_PHILOX> {
     uint32_t a, b;
-    uint32_t key, pixel, sample, cb;
+    uint32_t key, pixel, sample, cb, seg_base;
     uint32_t c[4];
     RTW_DEV void init(uint32_t k, uint32_t px, uint32_t smp, uint32_t wa, uint32_t wb) {
-        key = k; pixel = px; sample = smp; a = wa; b = wb; cb = 0xffffffffu;
+        key = k; pixel = px; sample = smp; a = wa; b = wb; cb = 0xffffffffu; seg_base = wa;
         c[0] = c[1] = c[2] = c[3] = 0;
     }
     RTW_DEV float next1() {
@@ -177,6 +179,16 @@ struct Rng<RTW_RNG_PHILOX> {
         return u24(v);
     }
     RTW_DEV float randf1() { return next1(); }
+    // the closest-hit program of every segment starts at a fresh block (see the oracle): wave-coherent refills
+    RTW_DEV void align_block() { a = (a + 3u) & ~3u; seg_base = a; }
+    // Russian-roulette draw: a fifth uniform from the low bytes of words 0..2 of the block this segment used last
+    // (see the oracle's rng_rr): a Lambertian segment then needs one Philox block, not two.
+    RTW_DEV float rr_draw() {
+        const uint32_t blk = (a == seg_base) ? (a >> 2) : ((a - 1u) >> 2);
+        if (blk != cb) { philox4x32_10(pixel, sample, blk, 1u, key, 0u, c); cb = blk; }
+        const uint32_t v = ((c[0] & 0xffu) << 16) | ((c[1] & 0xffu) << 8) | (c[2] & 0xffu);
+        return (float)v * (1.0f / 16777216.0f);
+    }
     RTW_DEV float ray_time(uint32_t depth) {
         uint32_t o[4];
         philox4x32_10(pixel, sample, depth >> 2, 2u, key, 0u, o);
@@ -193,7 +205,7 @@ struct BvhNode {
     uint32_t count;
 };
 
-// Per-primitive hit record baked at upload (64 B, fetched with one burst of four 16-byte loads once
+// Per-primitive hit record baked at upload (96 B, fetched with a burst of 16-byte loads once
 // the closest hit is known): material + its constant texture colour (texture/constantTexture.cu:5-10,
 // nullTexture.cu:7-12) and everything the shading normal needs, so that no primitive / transform
 // record has to be re-read per lane after traversal.
@@ -207,7 +219,11 @@ struct HitRec {
     float inv_r;        // spheres: 1/radius (IEEE division, done once on the host)
     float nx, ny, nz;   // HK_CONST_NORMAL: world shading normal (rectangles, volumes); spheres: centre
     int32_t xform;
-    float pad[4];
+    // HK_CONST_NORMAL: the orthonormal basis onb::buildFromW(normal) of lib/onb.cuh:20-32, computed once on the
+    // host with the same fp32 operations (u = cross(w,v), v = normalize(cross(w,a)), w = normalize(n))
+    float ux, uy, uz, pad0;
+    float vx, vy, vz, pad1;
+    float wx, wy, wz, pad2;
 };
 
 // Small-scene candidate lists, built at upload (rtw_upload_scene). 32-byte records so that one
@@ -566,7 +582,14 @@ RTW_DEV HitRec load_hitrec(const DScene& sc, int prim) {
     h.mat_type = (int)a.x; h.bsdf_eval = (int)a.y; h.param = __uint_as_float(a.z); h.kind = (int)a.w;
     h.r = __uint_as_float(b.x); h.g = __uint_as_float(b.y); h.b = __uint_as_float(b.z); h.inv_r = __uint_as_float(b.w);
     h.nx = __uint_as_float(c.x); h.ny = __uint_as_float(c.y); h.nz = __uint_as_float(c.z); h.xform = (int)c.w;
-    h.pad[0] = h.pad[1] = h.pad[2] = h.pad[3] = 0.f;
+    h.ux = h.uy = h.uz = h.vx = h.vy = h.vz = h.wx = h.wy = h.wz = 0.f;
+    h.pad0 = h.pad1 = h.pad2 = 0.f;
+    if (h.kind == HK_CONST_NORMAL && h.mat_type == RTW_MAT_LAMBERTIAN) {
+        const u32x4 d = q[3], e = q[4], f = q[5];
+        h.ux = __uint_as_float(d.x); h.uy = __uint_as_float(d.y); h.uz = __uint_as_float(d.z);
+        h.vx = __uint_as_float(e.x); h.vy = __uint_as_float(e.y); h.vz = __uint_as_float(e.z);
+        h.wx = __uint_as_float(f.x); h.wy = __uint_as_float(f.y); h.wz = __uint_as_float(f.z);
+    }
     return h;
 }
 

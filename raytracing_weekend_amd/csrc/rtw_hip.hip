@@ -283,6 +283,26 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
                 if (p.flip && !rtwbvh::is_volume(p.type)) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
                 if (p.xform != 0) { float w[3]; xfn(n[0], n[1], n[2], w); n[0] = w[0]; n[1] = w[1]; n[2] = w[2]; }
                 s.nx = n[0]; s.ny = n[1]; s.nz = n[2];
+                // onb::buildFromW (lib/onb.cuh:20-32) with the device's fp32 operation order
+                auto nrm = [](const float* a3, float* o3) {
+                    float dd = std::fmaf(a3[2], a3[2], std::fmaf(a3[1], a3[1], a3[0] * a3[0]));
+                    float inv = 1.0f / std::sqrt(dd);
+                    o3[0] = a3[0] * inv; o3[1] = a3[1] * inv; o3[2] = a3[2] * inv;
+                };
+                auto crs = [](const float* a3, const float* b3, float* o3) {
+                    o3[0] = std::fmaf(a3[1], b3[2], -(a3[2] * b3[1]));
+                    o3[1] = std::fmaf(a3[2], b3[0], -(a3[0] * b3[2]));
+                    o3[2] = std::fmaf(a3[0], b3[1], -(a3[1] * b3[0]));
+                };
+                float w3[3], a3[3], t3[3], v3_[3], u3[3];
+                nrm(n, w3);
+                if (w3[0] > 0.9f || w3[0] < -0.9f) { a3[0] = 0.f; a3[1] = 1.f; a3[2] = 0.f; } else { a3[0] = 1.f; a3[1] = 0.f; a3[2] = 0.f; }
+                crs(w3, a3, t3);
+                nrm(t3, v3_);
+                crs(w3, v3_, u3);
+                s.ux = u3[0]; s.uy = u3[1]; s.uz = u3[2];
+                s.vx = v3_[0]; s.vy = v3_[1]; s.vz = v3_[2];
+                s.wx = w3[0]; s.wy = w3[1]; s.wz = w3[2];
             }
         }
         if (m.texture >= 0) {

@@ -169,6 +169,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         }
         return EV_MISS;
     }
+    g.align_block();
     const HitRec hr = load_hitrec(sc, prim);
     v3 hp, hn;
     hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
@@ -179,10 +180,15 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     bool specular = false;
     if (mtype == RTW_MAT_LAMBERTIAN) {
         // lambertianMaterial.cu:41-71, onb.cuh:20-32, sampling.cuh:49-60 (Q1)
-        v3 w = normalize3(hn);
-        v3 a = (w.x > 0.9f || w.x < -0.9f) ? V(0.f, 1.f, 0.f) : V(1.f, 0.f, 0.f);
-        v3 v = normalize3(cross3(w, a));
-        v3 u = cross3(w, v);
+        v3 u, v, w;
+        if (hr.kind == HK_CONST_NORMAL) {  // basis baked per primitive at upload, same operations
+            u = V(hr.ux, hr.uy, hr.uz); v = V(hr.vx, hr.vy, hr.vz); w = V(hr.wx, hr.wy, hr.wz);
+        } else {
+            w = normalize3(hn);
+            v3 a = (w.x > 0.9f || w.x < -0.9f) ? V(0.f, 1.f, 0.f) : V(1.f, 0.f, 0.f);
+            v = normalize3(cross3(w, a));
+            u = cross3(w, v);
+        }
         float r1 = g.next1();
         float r2 = g.next1();
         float sn, cs;
@@ -337,7 +343,7 @@ RTW_DEV bool shade_b(const uint32_t depth, const uint32_t max_depth, Rng<KIND>& 
     T = vmul(T, att);
     if (2u <= depth) {  // raygen.cu:74-82
         float p = __builtin_fmaxf(__builtin_fmaxf(T.x, T.y), T.z);
-        if (p < g.next1()) return false;
+        if (p < g.rr_draw()) return false;
         T = vscale(T, 1.0f / p);
     }
     return depth + 1u < max_depth;
