@@ -525,7 +525,19 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
 
     /* color(): raygen.cu:92-95 */
     if (g.kind == RTW_RNG_TEA_LCG) { g.lcg[1] = g.lcg[0]; g.lcg[2] = g.lcg[0]; }
-    float gather_time = fmaf(rng_next(&g, 0), cam->time1 - cam->time0, cam->time0);
+    /* raygen.cu:95. Philox: the fifth raygen draw is cut from the low bytes of block 0 of stream 0 (whose four
+     * 24-bit uniforms were the jitter and lens draws), so that a camera path costs one raygen block */
+    float r_gather;
+    if (g.kind == RTW_RNG_TEA_LCG) {
+        r_gather = rng_next(&g, 0);
+    } else {
+        uint32_t ctr[4] = {g.pixel, g.sample, 0u, 0u};
+        uint32_t key[2] = {g.key0, 0u};
+        uint32_t out[4];
+        rtwo_philox4x32_10(ctr, key, out);
+        r_gather = (float)(((out[0] & 0xffu) << 16) | ((out[1] & 0xffu) << 8) | (out[2] & 0xffu)) * (1.0f / 16777216.0f);
+    }
+    float gather_time = fmaf(r_gather, cam->time1 - cam->time0, cam->time0);
 
     v3 T = V(1.f, 1.f, 1.f), L = V(0.f, 0.f, 0.f);
     int depth = 0;

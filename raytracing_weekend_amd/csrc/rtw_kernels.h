@@ -42,7 +42,7 @@ struct PathBuf {
 struct KArgs {
     DScene sc;
     PathBuf in, out;
-    const uint2* hit;           // per input slot: t, (prim+1) | occluded<<31
+    const uint2* hit;           // per input slot: t, (prim+1) | probe queued<<30 | occluded<<31
     uint2* hit_out;             // hit records of the OUTPUT slots (k_trace: of the slots it reads)
     float4* lbuf;               // per path id: final radiance of the sample
     const uint32_t* cnt_in;     // live paths per region (input)
@@ -70,6 +70,16 @@ RTW_DEV void load_path(const PathBuf& B, size_t s, Path& p) {
     load_trace_part(B, s, p);
     const float4 d = B.p3[s], e = B.p4[s];
     const uint4 f = B.p5[s];
+    p.T = V(d.x, d.y, d.z); p.L = V(d.w, e.x, e.y); p.c = V(e.z, e.w, __uint_as_float(f.x));
+    p.w0 = f.y; p.a = f.z; p.b = f.w;
+}
+// k_shade's view: everything but the queued probe's direction (plane p2 belongs to k_trace; whether a probe was
+// queued and what it found comes back in the hit record)
+RTW_DEV void load_shade_part(const PathBuf& B, size_t s, Path& p) {
+    const float4 a = B.p0[s], b = B.p1[s], d = B.p3[s], e = B.p4[s];
+    const uint4 f = B.p5[s];
+    p.o = V(a.x, a.y, a.z); p.d = V(a.w, b.x, b.y); p.ray_time = b.z; p.gk = __float_as_uint(b.w);
+    p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;
     p.T = V(d.x, d.y, d.z); p.L = V(d.w, e.x, e.y); p.c = V(e.z, e.w, __uint_as_float(f.x));
     p.w0 = f.y; p.a = f.z; p.b = f.w;
 }
@@ -395,7 +405,7 @@ RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, uint32_t* st
         float st;
         int sprim;
         traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, stack, A.stack_stride, st, sprim);
-        occl = sprim >= 0 ? 0x80000000u : 0u;
+        occl = (sprim >= 0 ? 0x80000000u : 0u) | 0x40000000u;  // bit 30: a probe was queued
         n_rays++;
     }
     A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
@@ -446,8 +456,8 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             uint32_t o[4];
             philox4x32_10(pixel, sample, 0u, 0u, A.seed, 0u, o);
             r0 = u24(o[0]); r1 = u24(o[1]); r2 = u24(o[2]); r3 = u24(o[3]);
-            philox4x32_10(pixel, sample, 1u, 0u, A.seed, 0u, o);
-            r4 = u24(o[0]);
+            // fifth raygen draw (gather time) from the block's spare low bytes: one raygen block per camera path
+            r4 = (float)(((o[0] & 0xffu) << 16) | ((o[1] & 0xffu) << 8) | (o[2] & 0xffu)) * (1.0f / 16777216.0f);
             g.init(A.seed, pixel, sample, 0u, sample);
             p.w0 = pixel;
         }
@@ -550,17 +560,17 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_shade(const KArgs A) 
         p.gk = 0; p.ltmax = -1.f;
         if (valid) {
             const size_t slot = (size_t)region * A.region_cap + idx;
-            load_path(A.in, slot, p);
+            load_shade_part(A.in, slot, p);
             const uint2 h = A.hit[slot];
             // the light sample queued by the previous bounce (closehit.cu:103-113), now that its probe is back
-            if (p.ltmax >= 0.0f && !(h.y & 0x80000000u)) p.L = vadd(p.L, p.c);
+            if ((h.y & 0xc0000000u) == 0x40000000u) p.L = vadd(p.L, p.c);
             if (p.gk & kZombie) {
                 finish_path(A, path_id_of<KIND>(A, p), p.L);
             } else {
                 Rng<KIND> g;
                 rng_from_path<KIND>(g, A.seed, p);
                 const float gt = gather_time_of(A, p.gk);
-                const int prim = (int)(h.y & 0x7fffffffu) - 1;
+                const int prim = (int)(h.y & 0x3fffffffu) - 1;
                 v3 so, sd, att, radiance;
                 Nee nee;
                 const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, __uint_as_float(h.x), prim, so, sd, att, radiance, nee);
