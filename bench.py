@@ -164,15 +164,18 @@ def main():
                        "partition": f"{world} row tile(s) of {max_rows} rows, one RCCL gather per step" if world > 1 else "single tile",
                        "segments_per_sample": round(segments / samples, 4),
                        "shadow_rays_per_sample": round(shadow / samples, 4),
-                       "paths_in_flight": int(os.environ.get("RTW_POOL_PATHS", 1 << 28))},
+                       "paths_in_flight": int(os.environ.get("RTW_POOL_PATHS", 1 << 28)),
+                       "lanes": int(os.environ.get("RTW_LANES", 2))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "kernel": names[dom], "launches": int(k_n[dom]),
                          "avg_launch_us": round(k_s[dom] / k_n[dom] * 1e6, 3) if k_n[dom] else None,
                          "algorithmic_bytes_per_launch": round(128.0 * dom_units / k_n[dom], 1) if k_n[dom] else None,
+                         "note": "two batches are in flight on two streams (lanes), so a kernel's own launch duration "
+                                 "includes sharing the GPU with the other lane's kernels; whole_loop is the unshared figure",
                          "whole_loop": {"achieved": round(loop_achieved, 2), "frac": round(loop_achieved / HBM_PEAK_GBS, 5),
                                         "seconds": round(b_s, 4), "launches": int(b_n),
-                                        "note": "128 B x all segments / device time of the wavefront loops (all four kernels)"},
+                                        "note": "128 B x all segments / device time of the render calls (all four kernels, both lanes)"},
                          "per_kernel": {names[i]: {"seconds": round(k_s[i], 4), "launches": int(k_n[i]), "units": int(k_seg[i])}
                                         for i in range(4)},
                          "render_device_seconds_rank0": round(r_s, 4)},

@@ -1,0 +1,38 @@
+"""Measures every configuration of BASELINE.json on one MI355X (not the headline bench: that is bench.py) and
+checks a row band of each against the CPU oracle. Prints one JSON object per configuration."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from raytracing_weekend_amd import abi
+import oracle
+
+CONFIGS = [
+    ("C1 Cornell 200x200 16spp depth 4", 0, 200, 200, 16, 4),
+    ("C2 Cornell 800x800 1024spp depth 50", 0, 800, 800, 1024, 50),
+    ("C3 random spheres 1920x1080 512spp depth 50", 1, 1920, 1080, 512, 50),
+    ("C4 Cornell+fog 1920x1080 2048spp depth 50", 3, 1920, 1080, 2048, 50),
+    ("Target Cornell 1920x1080 4096spp depth 50", 0, 1920, 1080, 4096, 50),
+    ("C5-tile Cornell 7680x4320 tile rows 0-539 (1/8), 256spp depth 50", 0, 7680, 4320, 256, 50),
+]
+r = abi.Renderer(0)
+for name, scene, w, h, spp, depth in CONFIGS:
+    blob = abi.build_scene(scene, w, h)
+    r.upload_scene(blob)
+    rows = (0, 540) if "tile" in name else (0, h)
+    p = abi.make_params(w, h, spp, depth, row0=rows[0], row1=rows[1])
+    r.render(abi.make_params(w, h, min(spp, 8), depth, row0=rows[0], row1=rows[1]))  # warm-up / allocation
+    t = time.perf_counter(); img, st = r.render(p); wall = time.perf_counter() - t
+    # parity on a band through the middle, at low spp (the oracle is slow)
+    band = (rows[0] + (rows[1] - rows[0]) // 2, rows[0] + (rows[1] - rows[0]) // 2 + 4)
+    pb = abi.make_params(w, h, min(spp, 4), depth, row0=band[0], row1=band[1])
+    g, _ = r.render(pb); o, _ = oracle.render(blob, pb, threads=32)
+    rmse = float(np.sqrt(np.mean((g[..., :3].astype(np.float64) - o[..., :3]) ** 2)))
+    print(json.dumps({"config": name, "samples": st.samples, "segments_per_sample": round(st.segments / st.samples, 4),
+                      "shadow_per_sample": round(st.shadow_rays / st.samples, 4), "device_seconds": round(st.seconds, 4),
+                      "Msamples_per_s": round(st.samples / st.seconds / 1e6, 1),
+                      "algorithmic_GBps": round(st.algorithmic_bytes / st.seconds / 1e9, 1),
+                      "frac_of_8TBps": round(st.algorithmic_bytes / st.seconds / 8e12, 4),
+                      "band_rmse_vs_oracle": rmse, "band_bit_exact": bool(np.array_equal(g, o)),
+                      "nan": int(np.isnan(img).sum())}), flush=True)
+r.close()
