@@ -53,6 +53,7 @@ struct rtw_ctx {
         hipEvent_t ev_done = nullptr, ev_free = nullptr;
         PathBuf buf[2] = {};
         uint2* hit[2] = {nullptr, nullptr};
+        void* slab[2] = {nullptr, nullptr};  // one allocation per ping-pong set: six planes + hit records, staggered
         float4* lbuf = nullptr;
         uint32_t* cnt = nullptr;
         size_t cnt_words = 0;
@@ -83,10 +84,9 @@ int fail(rtw_ctx* c, int code, const std::string& msg) {
 
 void free_lane(rtw_ctx::Lane& L) {
     for (int b = 0; b < 2; b++) {
-        void* pl[6] = {L.buf[b].p0, L.buf[b].p1, L.buf[b].p2, L.buf[b].p3, L.buf[b].p4, L.buf[b].p5};
-        for (void* q : pl) if (q) (void)hipFree(q);
+        if (L.slab[b]) (void)hipFree(L.slab[b]);
+        L.slab[b] = nullptr;
         L.buf[b] = PathBuf{};
-        if (L.hit[b]) (void)hipFree(L.hit[b]);
         L.hit[b] = nullptr;
     }
     if (L.lbuf) (void)hipFree(L.lbuf);
@@ -109,14 +109,20 @@ int ensure_lane(rtw_ctx* c, rtw_ctx::Lane& L, size_t paths, size_t cnt_words) {
     }
     if (paths > L.paths) {
         free_lane(L);
+        // The planes of one set are read and written at the same slot index by every wave. Equal-sized separate
+        // allocations would put slot s of all planes on the same HBM channel; inside one slab each plane starts
+        // at an optional extra offset (RTW_PLANE_STAGGER bytes apart; measured: no effect on MI355X, default 0).
+        size_t stagger = 0;
+        if (const char* e = getenv("RTW_PLANE_STAGGER")) stagger = (size_t)atoll(e) & ~(size_t)255;
+        const size_t plane = (paths * sizeof(float4) + 4095) & ~(size_t)4095;
         for (int b = 0; b < 2; b++) {
-            HIP_TRY(c, hipMalloc(&L.buf[b].p0, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&L.buf[b].p1, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&L.buf[b].p2, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&L.buf[b].p3, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&L.buf[b].p4, paths * sizeof(float4)));
-            HIP_TRY(c, hipMalloc(&L.buf[b].p5, paths * sizeof(uint4)));
-            HIP_TRY(c, hipMalloc(&L.hit[b], paths * sizeof(uint2)));
+            const size_t total = 7 * plane + 8 * stagger + 4096;
+            HIP_TRY(c, hipMalloc(&L.slab[b], total));
+            char* base = (char*)L.slab[b];
+            auto at = [&](int k) { return base + (size_t)k * plane + (size_t)k * stagger; };
+            L.buf[b].p0 = (float4*)at(0); L.buf[b].p1 = (float4*)at(1); L.buf[b].p2 = (float4*)at(2);
+            L.buf[b].p3 = (float4*)at(3); L.buf[b].p4 = (float4*)at(4); L.buf[b].p5 = (uint4*)at(5);
+            L.hit[b] = (uint2*)at(6);
         }
         HIP_TRY(c, hipMalloc(&L.lbuf, paths * sizeof(float4)));
         L.paths = paths;
@@ -163,8 +169,8 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
         else hipLaunchKernelGGL((k_first<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
     case LK_SHADE:
-        if (lcg) hipLaunchKernelGGL((k_shade<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), lds, s, a);
-        else hipLaunchKernelGGL((k_shade<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), lds, s, a);
+        if (lcg) hipLaunchKernelGGL((k_shade<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), 0, s, a);
+        else hipLaunchKernelGGL((k_shade<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), 0, s, a);
         break;
     case LK_TRACE:
         hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), lds, s, a);
@@ -445,7 +451,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     // region capacity: a multiple of 256 paths, at least 16384, large enough that <= kMaxRegions regions cover the pool
     size_t region_cap = std::max<size_t>(kMinRegionCap, (((paths_max + kMaxRegions - 1) / kMaxRegions) + kBlock - 1) / kBlock * kBlock);
     const uint32_t regions_max = (uint32_t)((paths_max + region_cap - 1) / region_cap);
-    bool split_first = false, fuse_trace = false;
+    bool split_first = false;
     // Launch schedule of one batch. Wide bounces: one k_shade + one k_trace per bounce (split pipeline; scenes
     // whose intersection programs draw random numbers keep trace and shade fused in k_bounce instead).
     // Thin tail: k_bounce with several bounces in registers, in growing groups.
@@ -455,13 +461,12 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         const char* e = getenv("RTW_TAIL_START");
         const int tail_start = (e && *e) ? std::max(1, atoi(e)) : 6;
         const bool split = c->sc.n_vol == 0 && !(getenv("RTW_FUSED") && getenv("RTW_FUSED")[0] == '1');
-        fuse_trace = split && getenv("RTW_FUSE_TRACE") && getenv("RTW_FUSE_TRACE")[0] == '1';
         int d = 0, grp = 2, rep = 0;
         while (d < P->max_depth) {
             if (d < tail_start) {
                 if (split) {
                     // k_first has already traced and shaded depth 0
-                    if (d > 0) { if (!fuse_trace) sched.push_back({LK_TRACE, d, 1}); sched.push_back({LK_SHADE, d, 1}); }
+                    if (d > 0) { sched.push_back({LK_TRACE, d, 1}); sched.push_back({LK_SHADE, d, 1}); }
                 } else {
                     sched.push_back({LK_BOUNCE, d, 1});
                 }
@@ -552,7 +557,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             a.max_depth = (uint32_t)P->max_depth;
             a.stack_stride = kBlock;
             a.region_cap = (uint32_t)region_cap;
-            a.trace_first = (split_first ? 1u : 0u) | (fuse_trace ? 2u : 0u);
+            a.trace_first = split_first ? 1u : 0u;
             const uint32_t n_chunks = (uint32_t)((paths + kBlock - 1) / kBlock);
             // persistent grids: 8 workgroups per CU when a lane has the GPU to itself, 4 when two lanes share it
             uint32_t grid_mult = n_lanes > 1 ? 4u : 8u;
@@ -581,10 +586,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
                     a.out = L.buf[cur ^ 1];
                     a.hit_out = L.hit[cur ^ 1];
                     a.cnt_out = L.cnt + (ci + 1) * regions;
-                    // with the trace fused in, the last k_shade before the tail leaves its probes to k_bounce
-                    KArgs b = a;
-                    if (fuse_trace && st.kind == LK_SHADE && (si + 1 == sched.size() || sched[si + 1].kind != LK_SHADE)) b.trace_first &= ~2u;
-                    HIP_TRY_C(timed_launch(ls, st.kind, b, grid, lds));
+                    HIP_TRY_C(timed_launch(ls, st.kind, a, grid, st.kind == LK_BOUNCE ? lds : 0));
                     cur ^= 1;
                     ci++;
                 }

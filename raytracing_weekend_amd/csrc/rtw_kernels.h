@@ -378,19 +378,16 @@ RTW_DEV void finish_path(const KArgs& A, uint32_t path_id, v3 L) {
     A.lbuf[path_id] = make_float4(lx, ly, lz, 0.f);
 }
 // wave64 ballot + popcount prefix; one atomic per wave reserves its slice of the region's output
-RTW_DEV size_t compact_store(const KArgs& A, uint32_t region, bool keep, const Path& p) {
+RTW_DEV void compact_store(const KArgs& A, uint32_t region, bool keep, const Path& p) {
     const unsigned long long ballot = __ballot(keep);
-    if (!ballot) return 0;
+    if (!ballot) return;
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
     uint32_t base = 0;
     if ((threadIdx.x & 63u) == 0) base = atomicAdd(&A.cnt_out[region], (uint32_t)__popcll(ballot));
     base = __builtin_amdgcn_readfirstlane(base);
-    const size_t slot = (size_t)region * A.region_cap + base + before;
-    if (keep) store_path(A.out, slot, p);
-    return slot;
+    if (keep) store_path(A.out, (size_t)region * A.region_cap + base + before, p);
 }
-// The trace pass of one path (what k_trace does per lane), callable from a shading kernel right after it has
-// stored the path: radiance ray closest hit + queued shadow probe any-hit, result into the hit buffer.
+// The trace pass of one path: radiance ray closest hit + queued shadow probe any-hit, result into the hit buffer.
 RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, uint32_t* stack, uint32_t& n_rays) {
     NoRng ng;
     const float gt = gather_time_of(A, p.gk);
@@ -427,7 +424,7 @@ template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
-    uint32_t n_seg = 0, n_shadow = 0, n_rays = 0;
+    uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
     for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
         const uint32_t path_id = vc * kBlock + tid;
@@ -482,7 +479,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
         p.T = V(1.f, 1.f, 1.f); p.L = V(0.f, 0.f, 0.f); p.c = V(0.f, 0.f, 0.f);
         p.a = g.a; p.b = g.b;
         keep = true;
-        if (A.trace_first & 1u) {
+        if (A.trace_first) {
             // split pipeline: trace and shade the primary segment here (primary rays are coherent, so the fused
             // form costs no divergence and saves writing and re-reading 104 B per camera path, half of which
             // leave the scene at once in a 16:9 Cornell frame)
@@ -512,12 +509,9 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             }
         }
         }
-        const size_t oslot = compact_store(A, path_region, keep, p);
-        if ((A.trace_first & 2u) && keep) trace_path(A, p, oslot, s_stack + tid, n_rays);
+        compact_store(A, path_region, keep, p);
     }
     flush_stats(A, n_seg, n_shadow, RTW_K_FIRST);
-    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
-    if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
 
 // ------------------------------------------------------------------ k_trace
@@ -543,12 +537,14 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(const KArgs A) {
 }
 
 // ------------------------------------------------------------------ k_shade
+#ifndef RTW_SHADE_WAVES
+#define RTW_SHADE_WAVES RTW_MIN_WAVES
+#endif
 template <int KIND>
-__global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_shade(const KArgs A) {
-    extern __shared__ uint32_t s_stack[];
+__global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A) {
     RTW_WORKLIST_SHARED
     const uint32_t tid = threadIdx.x;
-    uint32_t n_seg = 0, n_shadow = 0, n_rays = 0;
+    uint32_t n_seg = 0, n_shadow = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
     for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
         uint32_t region, chunk, n_in;
@@ -595,12 +591,9 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_shade(const KArgs A) 
                 }
             }
         }
-        const size_t oslot = compact_store(A, region, keep, p);
-        if ((A.trace_first & 2u) && keep) trace_path(A, p, oslot, s_stack + tid, n_rays);
+        compact_store(A, region, keep, p);
     }
     flush_stats(A, n_seg, n_shadow, RTW_K_SHADE);
-    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
-    if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
 
 // ------------------------------------------------------------------ k_bounce (fused)
