@@ -157,6 +157,7 @@ struct Rng<RTW_RNG_TEA_LCG> {
     RTW_DEV float next1() { return lcg_rnd(a); }
     RTW_DEV float randf1() { return xorshift_randf(a); }
     RTW_DEV void align_block() {}
+    RTW_DEV void warm() {}
     RTW_DEV float rr_draw() { return lcg_rnd(a); }  // raygen.cu:77
     RTW_DEV float ray_time(uint32_t) { return lcg_rnd(b); }
 };
@@ -181,6 +182,12 @@ struct Rng<RTW_RNG_PHILOX> {
     RTW_DEV float randf1() { return next1(); }
     // the closest-hit program of every segment starts at a fresh block (see the oracle): wave-coherent refills
     RTW_DEV void align_block() { a = (a + 3u) & ~3u; seg_base = a; }
+    // generate the block the next draw comes from now, while the whole wave is still on one code path
+    // (the material branches then find it cached instead of each running its own copy of the ten rounds)
+    RTW_DEV void warm() {
+        const uint32_t blk = a >> 2;
+        if (blk != cb) { philox4x32_10(pixel, sample, blk, 1u, key, 0u, c); cb = blk; }
+    }
     // Russian-roulette draw: a fifth uniform from the low bytes of words 0..2 of the block this segment used last
     // (see the oracle's rng_rr): a Lambertian segment then needs one Philox block, not two.
     RTW_DEV float rr_draw() {

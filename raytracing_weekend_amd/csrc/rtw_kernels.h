@@ -181,6 +181,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     }
     g.align_block();
     const HitRec hr = load_hitrec(sc, prim);
+    if (hr.mat_type != RTW_MAT_DIFFUSE_LIGHT && hr.mat_type != RTW_MAT_NORMAL) g.warm();
     v3 hp, hn;
     hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
     const int mtype = hr.mat_type;
