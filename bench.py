@@ -60,6 +60,9 @@ def main():
     ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (a reduced-spp line is not the headline metric)")
     ap.add_argument("--rng", type=int, default=0, help="0 Philox4x32-10 (default), 1 the reference's TEA+LCG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL over xGMI) or gloo "
+                                                    "(rehearsal on one GPU: ranks share device 0, tiles are gathered through host memory)")
+    ap.add_argument("--check", action="store_true", help="rank 0 re-renders the full frame alone and asserts the gathered image is identical")
     args = ap.parse_args()
 
     import torch
@@ -73,11 +76,15 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     blob = abi.build_scene(0, WIDTH, HEIGHT)
     from raytracing_weekend_amd.dist import partition_rows
@@ -86,16 +93,19 @@ def main():
     max_rows = max(rows[g + 1] - rows[g] for g in range(world))
     params = abi.make_params(WIDTH, HEIGHT, args.spp, DEPTH, seed=SEED, row0=row0, row1=row1, rng_kind=args.rng)
 
-    r = abi.Renderer(local_rank)
+    r = abi.Renderer(dev_index)
     r.upload_scene(blob)
     tile = torch.zeros((max_rows, WIDTH, 4), dtype=torch.float32, device=dev)
-    gathered = [torch.empty_like(tile) for _ in range(world)] if (world > 1 and rank == 0) else None
+    host_gather = world > 1 and args.backend != "nccl"
+    gdev = torch.device("cpu") if host_gather else dev
+    gathered = [torch.empty((max_rows, WIDTH, 4), dtype=torch.float32, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
     stream = torch.cuda.current_stream(dev).cuda_stream
 
     def step():
         st = r.render_device(params, tile.data_ptr(), stream)
         if world > 1:
-            dist.gather(tile, gathered, dst=0)  # the one collective: row tiles -> rank 0 over xGMI
+            # the one collective: row tiles -> rank 0 (RCCL over xGMI; through host memory in the gloo rehearsal)
+            dist.gather(tile.cpu() if host_gather else tile, gathered, dst=0)
         return st
 
     def fence():
@@ -124,6 +134,13 @@ def main():
     dt_max = float(t.item())
     segments, samples, shadow = (float(x) for x in agg.tolist())
 
+    if args.check and rank == 0:
+        full = torch.cat([gathered[g][: rows[g + 1] - rows[g]] for g in range(world)], dim=0).cpu() if world > 1 else tile[: rows[1]].cpu()
+        alone = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
+        r.render_device(abi.make_params(WIDTH, HEIGHT, args.spp, DEPTH, seed=SEED, rng_kind=args.rng), alone.data_ptr(), stream)
+        torch.cuda.synchronize(dev)
+        if not torch.equal(full, alone.cpu()):
+            raise SystemExit("gathered row tiles differ from the single-tile render")
     if rank == 0:
         # Dominant kernel of rank 0 = the wavefront kernel with the largest summed device time. Its
         # algorithmic bytes are 128 B per radiance segment it processed (64 B of SoA path state read

@@ -207,3 +207,24 @@ def test_render_into_device_memory_matches_host_path(gpu):
     st = gpu.render_device(p, t.data_ptr(), torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     assert np.array_equal(t.cpu().numpy(), host) and st.samples == 32 * 96 * 4
+
+
+def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
+    """The N>1 path of bench.py on the real kernels: two ranks (both on device 0), row tiles, one gather
+    (gloo through host memory here, RCCL on a multi-GPU node), image identical to the single-tile render."""
+    import json
+    import subprocess
+    import sys
+    root = abi.REPO_DIR
+    env = dict(os.environ, RTW_POOL_PATHS=str(1 << 22), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--spp", "4", "--backend", "gloo", "--check", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
+    assert d["config"]["segments_per_sample"] > 1.0
+    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
