@@ -87,11 +87,13 @@ def main():
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     blob = abi.build_scene(0, WIDTH, HEIGHT)
-    from raytracing_weekend_amd.dist import partition_rows
-    rows = partition_rows(HEIGHT, world)
-    row0, row1 = rows[rank], rows[rank + 1]
-    max_rows = max(rows[g + 1] - rows[g] for g in range(world))
-    params = abi.make_params(WIDTH, HEIGHT, args.spp, DEPTH, seed=SEED, row0=row0, row1=row1, rng_kind=args.rng)
+    from raytracing_weekend_amd.dist import interleaved_shard
+    # interleaved rows: rank g renders rows g, g+N, g+2N ... (balanced; contiguous tiles of a Cornell box are not)
+    row0, row1, row_stride, my_rows = interleaved_shard(HEIGHT, world, rank)
+    n_rows = [interleaved_shard(HEIGHT, world, g)[3] for g in range(world)]
+    max_rows = max(n_rows)
+    params = abi.make_params(WIDTH, HEIGHT, args.spp, DEPTH, seed=SEED, row0=row0, row1=row1, rng_kind=args.rng,
+                             row_stride=row_stride)
 
     r = abi.Renderer(dev_index)
     r.upload_scene(blob)
@@ -135,7 +137,9 @@ def main():
     segments, samples, shadow = (float(x) for x in agg.tolist())
 
     if args.check and rank == 0:
-        full = torch.cat([gathered[g][: rows[g + 1] - rows[g]] for g in range(world)], dim=0).cpu() if world > 1 else tile[: rows[1]].cpu()
+        full = torch.empty((HEIGHT, WIDTH, 4), dtype=torch.float32)
+        for g in range(world):
+            full[g::world] = (gathered[g] if world > 1 else tile)[: n_rows[g]].cpu()
         alone = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
         r.render_device(abi.make_params(WIDTH, HEIGHT, args.spp, DEPTH, seed=SEED, rng_kind=args.rng), alone.data_ptr(), stream)
         torch.cuda.synchronize(dev)
@@ -178,7 +182,7 @@ def main():
             "config": {"workload": f"Cornell box (reference scene 0) {WIDTH}x{HEIGHT}, {args.spp} spp, max depth {DEPTH}, "
                                    f"NEE mixture PDF (cosine + light rect), RR from depth 2, "
                                    f"{'Philox4x32-10' if args.rng == 0 else 'TEA+LCG'} seed 0x{SEED:x}",
-                       "partition": f"{world} row tile(s) of {max_rows} rows, one RCCL gather per step" if world > 1 else "single tile",
+                       "partition": f"{world} interleaved row shards (rank g: rows g, g+{world}, ...; {max_rows} rows each), one RCCL gather per step" if world > 1 else "single tile",
                        "segments_per_sample": round(segments / samples, 4),
                        "shadow_rays_per_sample": round(shadow / samples, 4),
                        "paths_in_flight": int(os.environ.get("RTW_POOL_PATHS", 1 << 28)),

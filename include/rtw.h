@@ -174,11 +174,14 @@ typedef struct rtw_params {
     int32_t spp;               /* samples per pixel rendered by this call                       */
     int32_t max_depth;         /* SysParamter.maxRayDepth                                       */
     uint32_t seed;
-    int32_t row0, row1;        /* rows [row0,row1) of the full image are rendered (row-tile shard) */
+    int32_t row0, row1;        /* rows [row0,row1) of the full image are rendered (row shard of one GPU)      */
     int32_t rng_kind;          /* rtw_rng_kind                                                  */
     int32_t sample_offset;     /* first sample index (progressive / resumed renders)            */
     int32_t samples_per_pass;  /* paths kept in flight = rows*width*samples_per_pass; 0 = auto  */
-    int32_t reserved[2];
+    int32_t row_stride;        /* 0 or 1: every row of [row0,row1). k > 1: rows row0, row0+k, row0+2k ... < row1
+                                  (interleaved shard: rank g of N uses row0=g, row1=height, row_stride=N, which
+                                  balances the ranks); the output holds those rows consecutively               */
+    int32_t reserved;
 } rtw_params;
 
 /* kernels of the wavefront loop, index into the per-kernel arrays of rtw_stats */

@@ -736,9 +736,15 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
     return L;
 }
 
-static void render_rows(const scene_t* sc, const rtw_params* P, int r0, int r1, float* out, counters_t* cn) {
+static int row_stride_of(const rtw_params* P) { return P->row_stride > 1 ? P->row_stride : 1; }
+static int local_rows_of(const rtw_params* P) { int k = row_stride_of(P); return (P->row1 - P->row0 + k - 1) / k; }
+
+/* local rows [l0,l1) of the shard: local row l is image row row0 + l*row_stride */
+static void render_rows(const scene_t* sc, const rtw_params* P, int l0, int l1, float* out, counters_t* cn) {
     int W = P->width;
-    for (int y = r0; y < r1; y++) {
+    int k = row_stride_of(P);
+    for (int l = l0; l < l1; l++) {
+        int y = P->row0 + l * k;
         for (int x = 0; x < W; x++) {
             v3 sum = V(0.f, 0.f, 0.f);
             for (int s = 0; s < P->spp; s++) {
@@ -746,7 +752,7 @@ static void render_rows(const scene_t* sc, const rtw_params* P, int r0, int r1, 
                 sum = vadd(sum, L);
             }
             float n = (float)P->spp;
-            float* o = out + 4 * ((size_t)(y - P->row0) * (size_t)W + (size_t)x);
+            float* o = out + 4 * ((size_t)l * (size_t)W + (size_t)x);
             o[0] = sum.x / n; o[1] = sum.y / n; o[2] = sum.z / n; o[3] = 1.0f;
         }
     }
@@ -768,7 +774,7 @@ static void* job_main(void* arg) {
 
 static int check_params(const rtw_params* P) {
     if (!P || P->width <= 0 || P->height <= 0 || P->spp <= 0 || P->max_depth < 0) return RTW_ERR_INVALID_ARG;
-    if (P->row0 < 0 || P->row1 > P->height || P->row0 > P->row1) return RTW_ERR_INVALID_ARG;
+    if (P->row0 < 0 || P->row1 > P->height || P->row0 > P->row1 || P->row_stride < 0) return RTW_ERR_INVALID_ARG;
     if (P->rng_kind != RTW_RNG_PHILOX && P->rng_kind != RTW_RNG_TEA_LCG) return RTW_ERR_INVALID_ARG;
     return RTW_OK;
 }
@@ -781,7 +787,7 @@ int rtwo_render(const void* blob, size_t bytes, const rtw_params* P, float* rgba
     rc = check_params(P);
     if (rc) return rc;
     if (!rgba_out) return RTW_ERR_INVALID_ARG;
-    int rows = P->row1 - P->row0;
+    int rows = local_rows_of(P);
     if (threads < 1) threads = 1;
     if (threads > rows) threads = rows > 0 ? rows : 1;
     if (threads > 256) threads = 256;
@@ -790,8 +796,8 @@ int rtwo_render(const void* blob, size_t bytes, const rtw_params* P, float* rgba
     if (!jobs || !th) { free(jobs); free(th); return RTW_ERR_OOM; }
     for (int i = 0; i < threads; i++) {
         jobs[i].sc = &sc; jobs[i].P = P; jobs[i].out = rgba_out;
-        jobs[i].r0 = P->row0 + (int)(((int64_t)rows * i) / threads);
-        jobs[i].r1 = P->row0 + (int)(((int64_t)rows * (i + 1)) / threads);
+        jobs[i].r0 = (int)(((int64_t)rows * i) / threads);
+        jobs[i].r1 = (int)(((int64_t)rows * (i + 1)) / threads);
     }
     if (threads == 1) {
         job_main(&jobs[0]);

@@ -72,7 +72,7 @@ class SceneHeader(C.Structure):
 class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("seed", C.c_uint32), ("row0", C.c_int32), ("row1", C.c_int32), ("rng_kind", C.c_int32),
-                ("sample_offset", C.c_int32), ("samples_per_pass", C.c_int32), ("reserved", C.c_int32 * 2)]
+                ("sample_offset", C.c_int32), ("samples_per_pass", C.c_int32), ("row_stride", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -166,7 +166,7 @@ def parse_scene(blob):
 
 
 def make_params(width, height, spp, max_depth, seed=0x6314759, row0=0, row1=None, rng_kind=RTW_RNG_PHILOX,
-                sample_offset=0, samples_per_pass=0):
+                sample_offset=0, samples_per_pass=0, row_stride=0):
     p = Params()
     p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
     p.seed = seed
@@ -175,7 +175,14 @@ def make_params(width, height, spp, max_depth, seed=0x6314759, row0=0, row1=None
     p.rng_kind = rng_kind
     p.sample_offset = sample_offset
     p.samples_per_pass = samples_per_pass
+    p.row_stride = row_stride
     return p
+
+
+def local_rows(params):
+    """Number of image rows a render with these params produces."""
+    k = max(1, params.row_stride)
+    return max(0, (params.row1 - params.row0 + k - 1) // k)
 
 
 class Renderer:
@@ -198,7 +205,7 @@ class Renderer:
         self._check(self.lib.rtw_upload_scene(self.ctx, blob, len(blob)), "rtw_upload_scene")
 
     def render(self, params):
-        rows = params.row1 - params.row0
+        rows = local_rows(params)
         out = np.empty((rows, params.width, 4), dtype=np.float32)
         st = Stats()
         self._check(self.lib.rtw_render(self.ctx, C.byref(params), out.ctypes.data, C.byref(st)), "rtw_render")

@@ -151,6 +151,15 @@ int ensure_pool(rtw_ctx* c, int n_lanes, size_t paths, size_t npix, size_t cnt_w
     return RTW_OK;
 }
 
+// multiply-high constants for exact 32-bit division by an invariant d >= 1 (Granlund & Montgomery 1994)
+void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
+    uint32_t l = 0;
+    while (l < 32 && ((uint64_t)1 << l) < d) l++;
+    m = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << l) - d)) / d + 1);
+    s1 = l < 1 ? l : 1;
+    s2 = l > 0 ? l - 1 : 0;
+}
+
 size_t pool_target_paths() {
     const char* e = getenv("RTW_POOL_PATHS");
     if (e && *e) {
@@ -430,11 +439,12 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     if (P->width <= 0 || P->height <= 0 || P->spp <= 0 || P->max_depth < 0 || P->row0 < 0 || P->row1 > P->height || P->row0 > P->row1)
         return fail(c, RTW_ERR_INVALID_ARG, "bad render params");
     if (P->rng_kind != RTW_RNG_PHILOX && P->rng_kind != RTW_RNG_TEA_LCG) return fail(c, RTW_ERR_INVALID_ARG, "bad rng_kind");
-    if (P->sample_offset < 0 || P->samples_per_pass < 0) return fail(c, RTW_ERR_INVALID_ARG, "bad sample_offset/samples_per_pass");
+    if (P->sample_offset < 0 || P->samples_per_pass < 0 || P->row_stride < 0) return fail(c, RTW_ERR_INVALID_ARG, "bad sample_offset/samples_per_pass/row_stride");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
 
-    const size_t rows = (size_t)(P->row1 - P->row0);
+    const uint32_t row_stride = P->row_stride > 1 ? (uint32_t)P->row_stride : 1u;
+    const size_t rows = ((size_t)(P->row1 - P->row0) + row_stride - 1) / row_stride;
     const size_t npix = rows * (size_t)P->width;
     if (stats) memset(stats, 0, sizeof *stats);
     if (npix == 0) return RTW_OK;
@@ -552,6 +562,9 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             a.width = (uint32_t)P->width;
             a.height = (uint32_t)P->height;
             a.row0 = (uint32_t)P->row0;
+            a.row_stride = row_stride;
+            magic_div((uint32_t)P->width, a.divw_m, a.divw_s1, a.divw_s2);
+            magic_div(row_stride, a.divs_m, a.divs_s1, a.divs_s2);
             a.sample0 = (uint32_t)(P->sample_offset + (int)s0);
             a.seed = P->seed;
             a.max_depth = (uint32_t)P->max_depth;
@@ -636,7 +649,8 @@ int rtw_render(rtw_ctx* c, const rtw_params* P, float* rgba_out, rtw_stats* stat
     if (!rgba_out) return fail(c, RTW_ERR_INVALID_ARG, "null output");
     if (!P) return fail(c, RTW_ERR_INVALID_ARG, "null params");
     if (P->width <= 0 || P->row0 < 0 || P->row1 < P->row0) return fail(c, RTW_ERR_INVALID_ARG, "bad render params");
-    const size_t npix = (size_t)(P->row1 - P->row0) * (size_t)P->width;
+    const size_t k_ = P->row_stride > 1 ? (size_t)P->row_stride : 1;
+    const size_t npix = (((size_t)(P->row1 - P->row0) + k_ - 1) / k_) * (size_t)P->width;
     HIP_TRY(c, hipSetDevice(c->device));
     if (npix > c->out_pix) {
         if (c->d_out) (void)hipFree(c->d_out);

@@ -49,6 +49,9 @@ struct KArgs {
     uint32_t* cnt_out;          // live paths per region (output), zeroed per batch
     unsigned long long* stats;  // [0] segments, [1] shadow probes, [2 + kind] segments per kernel kind
     uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, trace_first;
+    uint32_t row_stride;        // >= 1: local row l of the shard is image row row0 + l*row_stride
+    uint32_t divw_m, divw_s1, divw_s2;  // exact division by width (multiply-high + shifts)
+    uint32_t divs_m, divs_s1, divs_s2;  // exact division by row_stride
 };
 
 struct Path {
@@ -365,10 +368,22 @@ RTW_DEV void rng_from_path(Rng<KIND>& g, uint32_t seed, const Path& p) {
     if (KIND == RTW_RNG_TEA_LCG) g.init(seed, 0, 0, p.a, p.b);
     else g.init(seed, p.w0, p.b, p.a, p.b);  // Philox: w0 = global pixel, b = sample index
 }
+// n / d for any 32-bit n, with (m, s1, s2) precomputed on the host for the invariant divisor d (Granlund-Montgomery)
+RTW_DEV uint32_t fastdiv(uint32_t n, uint32_t m, uint32_t s1, uint32_t s2) {
+    const uint32_t t = __umulhi(m, n);
+    return (t + ((n - t) >> s1)) >> s2;
+}
 template <int KIND>
 RTW_DEV uint32_t path_id_of(const KArgs& A, const Path& p) {
     if (KIND == RTW_RNG_TEA_LCG) return p.w0;
-    return (p.b - A.sample0) * A.npix + (p.w0 - A.row0 * A.width);
+    // Philox paths carry the global pixel (their stream key); the radiance slot is indexed by the shard-local pixel
+    uint32_t local = p.w0 - A.row0 * A.width;
+    if (A.row_stride > 1) {
+        const uint32_t y = fastdiv(p.w0, A.divw_m, A.divw_s1, A.divw_s2);
+        const uint32_t x = p.w0 - y * A.width;
+        local = fastdiv(y - A.row0, A.divs_m, A.divs_s1, A.divs_s2) * A.width + x;
+    }
+    return (p.b - A.sample0) * A.npix + local;
 }
 RTW_DEV float gather_time_of(const KArgs& A, uint32_t gk) {
     return fma_((float)(gk & 0x00ffffffu) * (1.0f / 16777216.0f), A.sc.cam.time1 - A.sc.cam.time0, A.sc.cam.time0);
@@ -439,7 +454,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
         const uint32_t pl = path_id - slot * A.npix;
         const uint32_t yl = pl / A.width;
         const uint32_t x = pl - yl * A.width;
-        const uint32_t y = A.row0 + yl;
+        const uint32_t y = A.row0 + yl * A.row_stride;
         const uint32_t pixel = A.width * y + x;
         const uint32_t sample = A.sample0 + slot;
         Rng<KIND> g;

@@ -46,7 +46,7 @@ def load():
 
 def render(blob, params, threads=1):
     lib = load()
-    rows = params.row1 - params.row0
+    rows = abi.local_rows(params)
     out = np.empty((rows, params.width, 4), dtype=np.float32)
     st = abi.Stats()
     rc = lib.rtwo_render(blob, len(blob), C.byref(params), out.ctypes.data, C.byref(st), threads)

@@ -173,6 +173,15 @@ def test_full_size_tiles_batches_and_determinism(gpu):
         parts.append(img)
         seg += s.segments
     assert np.array_equal(np.concatenate(parts, axis=0), full) and seg == st.segments
+    # the interleaved shards bench.py uses for 8 GPUs (rank g: rows g, g+8, ...), and an odd count
+    for world in (8, 3):
+        out = np.empty_like(full)
+        for g in range(world):
+            p = abi.make_params(FULL_W, FULL_H, spp, depth, row0=g, row1=FULL_H, row_stride=world)
+            img, s = gpu.render(p)
+            assert img.shape[0] == abi.local_rows(p)
+            out[g::world] = img
+        assert np.array_equal(out, full)
     # sample ranges: spp 6 = samples [0,4) + [4,6) up to the final division
     a, _ = gpu.render(abi.make_params(FULL_W, FULL_H, 4, depth, row0=500, row1=540))
     b, _ = gpu.render(abi.make_params(FULL_W, FULL_H, 2, depth, row0=500, row1=540, sample_offset=4))

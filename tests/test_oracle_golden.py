@@ -50,6 +50,21 @@ def test_row_tiles_are_independent_of_the_partition(rng):
     assert np.array_equal(np.concatenate(parts, axis=0), full)
 
 
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_interleaved_row_shards_reassemble_the_frame(world):
+    blob = abi.build_scene(0, 40, 27)
+    full, st_full = oracle.render(blob, abi.make_params(40, 27, 3, 5), threads=4)
+    out = np.empty_like(full)
+    seg = 0
+    for g in range(world):
+        p = abi.make_params(40, 27, 3, 5, row0=g, row1=27, row_stride=world)
+        img, st = oracle.render(blob, p, threads=2)
+        assert img.shape[0] == abi.local_rows(p) == len(range(g, 27, world))
+        out[g::world] = img
+        seg += st.segments
+    assert np.array_equal(out, full) and seg == st_full.segments
+
+
 def test_sample_offset_selects_the_same_streams():
     blob = abi.build_scene(0, 32, 32)
     whole, _ = oracle.render(blob, abi.make_params(32, 32, 8, 5), threads=4)
