@@ -582,6 +582,71 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
 #undef RTW_ACCEPT
 }
 
+// Radiance ray (closest hit) and queued shadow probe (any hit) of one path in ONE walk over the small-scene
+// candidate lists: the two rays share their origin, so each group's object-space origin and each record's
+// scalar load and plane offset (k - o) are computed once. Per ray the arithmetic is exactly that of
+// traverse<>: same operations, same order, same tie rule (the images stay bit-identical).
+// Only for scenes without volume or moving-sphere candidates (n_vol == 0 && n_generic == 0).
+RTW_DEV void traverse_dual_brute(const DScene& sc, const v3 o, const v3 dr, const v3 ds, const bool do_r, const bool do_s,
+                                 const float smin, const float smax, float& best_t, int& best_prim, bool& occluded) {
+    const float rmin = 1e-6f;
+    best_t = 1.e27f;
+    best_prim = -1;
+    occluded = false;
+    for (int gi = 0; gi < sc.n_groups; gi++) {
+        const BruteGroup G = load_group(sc, gi);
+        v3 oo = o, ddr = dr, dds = ds;
+        if (G.xform != 0) {
+            M34 im = load_xf_inv(sc, G.xform);
+            oo = xf_point(im.m, o);
+            ddr = xf_vector(im.m, dr);
+            dds = xf_vector(im.m, ds);
+        }
+        int ri = G.first;
+        if (G.n_rx + G.n_ry + G.n_rz > 0) {
+            const v3 invr = recip3(ddr);
+            const v3 invs = recip3(dds);
+#define RTW_DUAL_RECT_LOOP(N_, OK_, IKR_, IKS_, OA_, DAR_, DAS_, OB_, DBR_, DBS_)                      \
+            for (int i = 0; i < (N_); i++, ri++) {                                                   \
+                const BruteRec R = load_rec(sc, ri);                                                 \
+                const float kmo = R.e - (OK_);                                                       \
+                {                                                                                    \
+                    const float t = kmo * (IKR_);                                                    \
+                    const float a = fma_(t, (DAR_), (OA_));                                          \
+                    const float b = fma_(t, (DBR_), (OB_));                                          \
+                    const bool hit = do_r & (t >= rmin) & (a >= R.a) & (a <= R.b) & (b >= R.c) & (b <= R.d); \
+                    const bool tie = (t == best_t) & (R.prim < best_prim);                           \
+                    const bool take = hit & ((t < best_t) | tie);                                    \
+                    best_t = take ? t : best_t;                                                      \
+                    best_prim = take ? R.prim : best_prim;                                           \
+                }                                                                                    \
+                {                                                                                    \
+                    const float t = kmo * (IKS_);                                                    \
+                    const float a = fma_(t, (DAS_), (OA_));                                          \
+                    const float b = fma_(t, (DBS_), (OB_));                                          \
+                    occluded |= do_s & (t >= smin) & (t < smax) & (a >= R.a) & (a <= R.b) & (b >= R.c) & (b <= R.d); \
+                }                                                                                    \
+            }
+            RTW_DUAL_RECT_LOOP(G.n_rx, oo.x, invr.x, invs.x, oo.y, ddr.y, dds.y, oo.z, ddr.z, dds.z)
+            RTW_DUAL_RECT_LOOP(G.n_ry, oo.y, invr.y, invs.y, oo.x, ddr.x, dds.x, oo.z, ddr.z, dds.z)
+            RTW_DUAL_RECT_LOOP(G.n_rz, oo.z, invr.z, invs.z, oo.x, ddr.x, dds.x, oo.y, ddr.y, dds.y)
+#undef RTW_DUAL_RECT_LOOP
+        }
+        for (int i = 0; i < G.n_sph; i++, ri++) {
+            const BruteRec R = load_rec(sc, ri);
+            const v3 c = V(R.a, R.b, R.c);
+            float t = 0.f;
+            const bool hit = do_r & sphere_roots(oo, ddr, c, R.d, rmin, RTW_FLT_MAX, t);
+            const bool tie = (t == best_t) & (R.prim < best_prim);
+            const bool take = hit & ((t < best_t) | tie);
+            best_t = take ? t : best_t;
+            best_prim = take ? R.prim : best_prim;
+            float ts = 0.f;
+            occluded |= do_s & sphere_roots(oo, dds, c, R.d, smin, smax, ts);
+        }
+    }
+}
+
 RTW_DEV HitRec load_hitrec(const DScene& sc, int prim) {
     const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.hitrec + prim);
     const u32x4 a = q[0], b = q[1], c = q[2];

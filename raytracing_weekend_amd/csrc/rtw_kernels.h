@@ -407,22 +407,30 @@ RTW_DEV void compact_store(const KArgs& A, uint32_t region, bool keep, const Pat
 RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, uint32_t* stack, uint32_t& n_rays) {
     NoRng ng;
     const float gt = gather_time_of(A, p.gk);
+    const bool do_r = !(p.gk & kZombie);
+    const bool do_s = p.ltmax >= 0.0f;
     float th = 0.f;
     int prim = -1;
-    if (!(p.gk & kZombie)) {
-        traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, stack, A.stack_stride, th, prim);
-        n_rays++;
-    }
     uint32_t occl = 0;
-    if (p.ltmax >= 0.0f) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
-        float st;
-        int sprim;
-        traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, stack, A.stack_stride, st, sprim);
-        occl = (sprim >= 0 ? 0x80000000u : 0u) | 0x40000000u;  // bit 30: a probe was queued
-        n_rays++;
+    if (!A.sc.use_bvh && A.sc.n_generic == 0) {
+        // small scenes: one shared walk for both rays
+        bool oc;
+        traverse_dual_brute(A.sc, p.o, p.d, p.ldir, do_r, do_s, 500 * 1.0e-7f, p.ltmax, th, prim, oc);
+        if (!do_r) { th = 0.f; prim = -1; }
+        if (do_s) occl = (oc ? 0x80000000u : 0u) | 0x40000000u;  // bit 30: a probe was queued
+    } else {
+        if (do_r) traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, stack, A.stack_stride, th, prim);
+        if (do_s) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
+            float st;
+            int sprim;
+            traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, stack, A.stack_stride, st, sprim);
+            occl = (sprim >= 0 ? 0x80000000u : 0u) | 0x40000000u;
+        }
     }
+    n_rays += (do_r ? 1u : 0u) + (do_s ? 1u : 0u);
     A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
 }
+
 RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow, int kind) {
     for (int off = 32; off > 0; off >>= 1) {
         n_seg += __shfl_down(n_seg, off);

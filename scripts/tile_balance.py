@@ -14,3 +14,14 @@ for n in (2, 4, 8):
         _, st = r.render(p)
         ts.append(st.seconds)
     print(n, "tiles: seconds", [round(t, 4) for t in ts], "max/mean %.3f" % (max(ts) / (sum(ts) / n)), "ideal speedup vs sum %.2f" % (sum(ts) / max(ts)))
+
+for n in (2, 4, 8):
+    ts = []
+    for g in range(n):
+        p = abi.make_params(W, H, SPP, D, row0=g, row1=H, row_stride=n)
+        r.render(abi.make_params(W, H, 8, D, row0=g, row1=H, row_stride=n))
+        _, st = r.render(p)
+        ts.append(st.seconds)
+    print(n, "interleaved shards: seconds", [round(t, 4) for t in ts], "max/mean %.3f" % (max(ts) / (sum(ts) / n)), "ideal speedup vs sum %.2f" % (sum(ts) / max(ts)))
+_, st1 = r.render(abi.make_params(W, H, SPP, D))
+print("single tile seconds", round(st1.seconds, 4))
