@@ -165,6 +165,27 @@ def parse_scene(blob):
     }
 
 
+def assemble_scene(parts):
+    """Inverse of parse_scene: serialise {"header", "prims", "xforms", "materials", "textures", "lights"} (ctypes
+    arrays or lists of the structs) into a blob; counts, offsets and total_bytes are recomputed."""
+    src = parts["header"]
+    h = SceneHeader.from_buffer_copy(bytes(src))
+    tables = [list(parts[k]) for k in ("prims", "xforms", "materials", "textures", "lights")]
+    h.n_prims, h.n_xforms, h.n_materials, h.n_textures, h.n_lights = (len(t) for t in tables)
+    sizes = [C.sizeof(t) for t in (Prim, Xform, Material, Texture, Light)]
+    offs = [(C.sizeof(SceneHeader) + 15) // 16 * 16]
+    for t, sz in zip(tables, sizes):
+        offs.append((offs[-1] + len(t) * sz + 15) // 16 * 16)
+    h.off_prims, h.off_xforms, h.off_materials, h.off_textures, h.off_lights = offs[:5]
+    h.total_bytes = offs[5]
+    buf = bytearray(offs[5])
+    buf[0:C.sizeof(SceneHeader)] = bytes(h)
+    for t, sz, off in zip(tables, sizes, offs):
+        for i, obj in enumerate(t):
+            buf[off + i * sz:off + (i + 1) * sz] = bytes(obj)
+    return bytes(buf)
+
+
 def make_params(width, height, spp, max_depth, seed=0x6314759, row0=0, row1=None, rng_kind=RTW_RNG_PHILOX,
                 sample_offset=0, samples_per_pass=0, row_stride=0):
     p = Params()

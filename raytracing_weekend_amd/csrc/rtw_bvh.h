@@ -101,8 +101,20 @@ inline Box world_bounds(const rtw_prim& p, const rtw_xform& xf) {
     return wb;
 }
 
+// What the GPU walks: one 64-byte record per INNER node holding the bounds of both children, so a traversal
+// step is one burst of four 16-byte loads and the child that is entered next needs no load of its own box.
+// A child reference is idx | count << 30: count > 0 (1 or 2) is a leaf whose idx is its first entry in
+// prim_order; count == 0 is an inner node and idx its wide-node index.
+struct WideNode {
+    float lmn[3]; uint32_t lref;
+    float lmx[3]; uint32_t pad0;
+    float rmn[3]; uint32_t rref;
+    float rmx[3]; uint32_t pad1;
+};
+
 struct Bvh {
     std::vector<Node> nodes;
+    std::vector<WideNode> wide;       // inner nodes only; wide[0] is the root
     std::vector<int32_t> prim_order;  // leaf entries -> primitive index
     int max_depth = 0;
 };
@@ -189,6 +201,30 @@ inline Bvh build_bvh(const rtw_prim* prims, uint32_t n_prims, const rtw_xform* x
     detail::build(items, 0, static_cast<int>(items.size()), 0, 1, out);
     out.prim_order.resize(items.size());
     for (size_t i = 0; i < items.size(); i++) out.prim_order[i] = items[i].prim;
+    // inner nodes -> wide records, numbered breadth-first so that a prefix of the array is the top of the tree
+    std::vector<int32_t> wid(out.nodes.size(), -1);
+    int32_t nw = 0;
+    if (out.nodes[0].count == 0) {
+        std::vector<uint32_t> queue{0u};
+        for (size_t q = 0; q < queue.size(); q++) {
+            const Node& nd = out.nodes[queue[q]];
+            wid[queue[q]] = nw++;
+            for (uint32_t c = 0; c < 2; c++)
+                if (out.nodes[nd.left_first + c].count == 0) queue.push_back(nd.left_first + c);
+        }
+    }
+    out.wide.resize((size_t)nw);
+    for (size_t i = 0; i < out.nodes.size(); i++) {
+        const Node& nd = out.nodes[i];
+        if (nd.count != 0) continue;
+        WideNode& w = out.wide[(size_t)wid[i]];
+        const Node& L = out.nodes[nd.left_first];
+        const Node& R = out.nodes[nd.left_first + 1];
+        for (int a = 0; a < 3; a++) { w.lmn[a] = L.mn[a]; w.lmx[a] = L.mx[a]; w.rmn[a] = R.mn[a]; w.rmx[a] = R.mx[a]; }
+        w.lref = (L.count ? L.left_first : (uint32_t)wid[nd.left_first]) | (L.count << 30);
+        w.rref = (R.count ? R.left_first : (uint32_t)wid[nd.left_first + 1]) | (R.count << 30);
+        w.pad0 = w.pad1 = 0;
+    }
     return out;
 }
 

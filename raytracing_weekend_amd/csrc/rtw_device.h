@@ -205,11 +205,12 @@ struct Rng<RTW_RNG_PHILOX> {
 };
 
 // ------------------------------------------------------------------ device scene
+// inner node of the BVH2 with the bounds of both children (rtw_bvh.h WideNode); ref = idx | leaf count << 30
 struct BvhNode {
-    float mn[3];
-    uint32_t left_first;
-    float mx[3];
-    uint32_t count;
+    float lmn[3]; uint32_t lref;
+    float lmx[3]; uint32_t pad0;
+    float rmn[3]; uint32_t rref;
+    float rmx[3]; uint32_t pad1;
 };
 
 // Per-primitive hit record baked at upload (96 B, fetched with a burst of 16-byte loads once
@@ -259,7 +260,8 @@ struct DScene {
     const BruteGroup* __restrict__ groups;   // small scenes: primitives regrouped by instance transform and kind
     const BruteRec* __restrict__ recs;
     int32_t n_prims, n_vol, n_tree, n_lights, sky_light, use_bvh, has_motion, n_groups;
-    int32_t n_generic, pad0, pad1, pad2;     // order[n_vol .. n_vol+n_generic): moving spheres, tested through the generic path
+    int32_t n_generic;                       // order[n_vol .. n_vol+n_generic): moving spheres, tested through the generic path
+    int32_t n_lds_nodes, stack_depth, pad2;  // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks
     rtw_camera cam;
     rtw_pdf pdf;
 };
@@ -313,12 +315,44 @@ RTW_DEV BruteRec load_rec(const DScene& sc, int i) {
     r.e = __uint_as_float(q[4]); r.prim = (int)q[5]; r.pad0 = 0; r.pad1 = 0;
     return r;
 }
-RTW_DEV BvhNode load_node(const DScene& sc, uint32_t i) {
-    const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + i);
-    u32x4 a = q[0], b = q[1];
+// Per-thread traversal memory: this thread's column of the LDS stack and the block's LDS copy of the top of the tree.
+struct TravMem {
+    uint32_t* stack;
+    uint32_t stride;
+    const u32x4* nodes;   // LDS, n_nodes * 4 vectors
+    uint32_t n_nodes;
+};
+
+// Every thread of the block calls this once before its first traverse<> (it holds a barrier).
+RTW_DEV TravMem trav_mem(const DScene& sc, uint32_t* lds, uint32_t block, uint32_t tid) {
+    TravMem tm;
+    tm.stack = lds + tid;
+    tm.stride = block;
+    u32x4* cache = (u32x4*)(lds + (uint32_t)sc.stack_depth * block);
+    tm.nodes = cache;
+    tm.n_nodes = (uint32_t)sc.n_lds_nodes;
+    if (tm.n_nodes) {
+        const u32x4* src = (const u32x4*)sc.nodes;
+        for (uint32_t i = tid; i < tm.n_nodes * 4u; i += block) cache[i] = src[i];
+        __syncthreads();
+    }
+    return tm;
+}
+
+RTW_DEV BvhNode load_node(const DScene& sc, const TravMem& tm, uint32_t i) {
+    u32x4 a, b, c, d;
+    if (i < tm.n_nodes) {
+        const u32x4* q = tm.nodes + 4u * i;
+        a = q[0]; b = q[1]; c = q[2]; d = q[3];
+    } else {
+        const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + i);
+        a = q[0]; b = q[1]; c = q[2]; d = q[3];
+    }
     BvhNode n;
-    n.mn[0] = __uint_as_float(a.x); n.mn[1] = __uint_as_float(a.y); n.mn[2] = __uint_as_float(a.z); n.left_first = a.w;
-    n.mx[0] = __uint_as_float(b.x); n.mx[1] = __uint_as_float(b.y); n.mx[2] = __uint_as_float(b.z); n.count = b.w;
+    n.lmn[0] = __uint_as_float(a.x); n.lmn[1] = __uint_as_float(a.y); n.lmn[2] = __uint_as_float(a.z); n.lref = a.w;
+    n.lmx[0] = __uint_as_float(b.x); n.lmx[1] = __uint_as_float(b.y); n.lmx[2] = __uint_as_float(b.z); n.pad0 = 0;
+    n.rmn[0] = __uint_as_float(c.x); n.rmn[1] = __uint_as_float(c.y); n.rmn[2] = __uint_as_float(c.z); n.rref = c.w;
+    n.rmx[0] = __uint_as_float(d.x); n.rmx[1] = __uint_as_float(d.y); n.rmx[2] = __uint_as_float(d.z); n.pad1 = 0;
     return n;
 }
 
@@ -441,16 +475,58 @@ RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, v3 inv, float tmin, flo
     }
 }
 
+// ---- BVH2 walk, shared by traverse<> and the refilling trace kernel (rtw_kernels.h k_trace_bvh) ----
+static constexpr uint32_t kBvhDone = 0xffffffffu;  // not an inner reference (count bits = 3), not a leaf that exists
+
+RTW_DEV uint32_t bvh_pop(const TravMem& tm, int& sp) {
+    if (sp == 0) return kBvhDone;
+    sp--;
+    return tm.stack[sp * tm.stride];
+}
+
+// One step through inner node `cur`: slab tests of both children against [tmin, best_t], nearer child first,
+// the other one pushed. Returns the next reference (inner or leaf), or kBvhDone when nothing is left.
+RTW_DEV uint32_t bvh_inner_step(const DScene& sc, const TravMem& tm, const v3 o, const v3 inv, float tmin, float best_t, uint32_t cur, int& sp) {
+    const BvhNode nd = load_node(sc, tm, cur);
+    float tn0, tn1;
+    bool h0, h1;
+    {
+        float ax = (nd.lmn[0] - o.x) * inv.x, bx = (nd.lmx[0] - o.x) * inv.x;
+        float ay = (nd.lmn[1] - o.y) * inv.y, by = (nd.lmx[1] - o.y) * inv.y;
+        float az = (nd.lmn[2] - o.z) * inv.z, bz = (nd.lmx[2] - o.z) * inv.z;
+        tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
+        float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
+        h0 = tn0 <= tfar * 1.00001f;
+    }
+    {
+        float ax = (nd.rmn[0] - o.x) * inv.x, bx = (nd.rmx[0] - o.x) * inv.x;
+        float ay = (nd.rmn[1] - o.y) * inv.y, by = (nd.rmx[1] - o.y) * inv.y;
+        float az = (nd.rmn[2] - o.z) * inv.z, bz = (nd.rmx[2] - o.z) * inv.z;
+        tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
+        float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
+        h1 = tn1 <= tfar * 1.00001f;
+    }
+    if (h0 && h1) {
+        const bool first0 = tn0 <= tn1;
+        tm.stack[sp * tm.stride] = first0 ? nd.rref : nd.lref;
+        sp++;
+        return first0 ? nd.lref : nd.rref;
+    }
+    if (h0) return nd.lref;
+    if (h1) return nd.rref;
+    return bvh_pop(tm, sp);
+}
+
 RTW_DEV bool uses_inv(int type) { return type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_VOLUME_BOX; }
 RTW_DEV v3 recip3(v3 d) { return V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 
 // Closest / any hit (optixTraverse at raygen.cu:41-54 and closehit.cu:27-40).
 // Candidate order (observable only through volume RNG draws and exact ties in t): volume
 // primitives in index order, then everything else with ties resolved to the lowest index.
-// stack: this thread's column of the LDS traversal stack (stride = block size).
+// tm: this thread's column of the LDS traversal stack and the block's LDS node cache (trav_mem).
 template <class RNG, bool ANY_HIT, bool SKIP_VOLUMES>
 RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, float ray_time, float gather_time, RNG& g,
-                      uint32_t* stack, uint32_t stack_stride, float& best_t, int& best_prim) {
+                      const TravMem& tm, float& best_t, int& best_prim) {
     best_t = tmax;
     best_prim = -1;
     // volumes first, in index order
@@ -532,52 +608,28 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
         return;
     }
     if (sc.n_tree <= 0) return;
-    // BVH2, per-lane stack staged in LDS
+    // BVH2, "while-while" walk: a tight loop descends through inner nodes (one 64-byte record per step carries
+    // both children's boxes), leaves wait on the per-lane LDS stack column like inner nodes and are tested when
+    // they come up. The boxes only cull, so the visiting order does not change the result.
     const v3 inv = recip3(d);
     int sp = 0;
-    uint32_t node = 0;
+    uint32_t cur = 0;
     for (;;) {
-        const BvhNode nd = load_node(sc, node);
-        if (nd.count == 0) {
-            uint32_t child[2] = {nd.left_first, nd.left_first + 1u};
-            float tn[2];
-            bool hit[2];
-#pragma unroll
-            for (int c = 0; c < 2; c++) {
-                const BvhNode ch = load_node(sc, child[c]);
-                float ax = (ch.mn[0] - o.x) * inv.x, bx = (ch.mx[0] - o.x) * inv.x;
-                float ay = (ch.mn[1] - o.y) * inv.y, by = (ch.mx[1] - o.y) * inv.y;
-                float az = (ch.mn[2] - o.z) * inv.z, bz = (ch.mx[2] - o.z) * inv.z;
-                float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
-                float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
-                tn[c] = tnear;
-                hit[c] = tnear <= tfar * 1.00001f;
-            }
-            if (hit[0] && hit[1]) {
-                bool first0 = tn[0] <= tn[1];
-                stack[sp * stack_stride] = first0 ? child[1] : child[0];
-                sp++;
-                node = first0 ? child[0] : child[1];
-                continue;
-            }
-            if (hit[0]) { node = child[0]; continue; }
-            if (hit[1]) { node = child[1]; continue; }
-        } else {
-            for (uint32_t k = 0; k < nd.count; k++) {
-                int pi = load_i32(sc.tree_prims + nd.left_first + k);
-                const rtw_prim pr = load_prim(sc, pi);
-                v3 po, pd, mt;
-                object_ray(sc, pr, o, d, ray_time, po, pd, mt);
-                v3 pinv = inv;
-                if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
-                float t;
-                // tie rule: on equal t the lower primitive index wins (== the oracle's index-order scan)
-                if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time, g, t)) { RTW_ACCEPT(t, pi) }
-            }
+        while ((cur >> 30) == 0u) cur = bvh_inner_step(sc, tm, o, inv, tmin, best_t, cur, sp);
+        if (cur == kBvhDone) break;
+        const uint32_t first = cur & 0x3fffffffu, cnt = cur >> 30;
+        for (uint32_t k = 0; k < cnt; k++) {
+            const int pi = load_i32(sc.tree_prims + first + k);
+            const rtw_prim pr = load_prim(sc, pi);
+            v3 po, pd, mt;
+            object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+            v3 pinv = inv;
+            if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
+            float t;
+            if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time, g, t)) { RTW_ACCEPT(t, pi) }
         }
-        if (sp == 0) break;
-        sp--;
-        node = stack[sp * stack_stride];
+        cur = bvh_pop(tm, sp);
+        if (cur == kBvhDone) break;
     }
 #undef RTW_ACCEPT
 }

@@ -45,6 +45,7 @@ struct rtw_ctx {
     DScene sc{};
     void* d_scene = nullptr;   // one allocation holding all scene tables
     int stack_depth = 0;
+    size_t lds_bytes = 0;
     // render pool
     // Two independent "lanes" (stream + path pool): consecutive batches alternate between them so that the
     // bandwidth-bound kernels of one batch overlap the compute- and latency-bound kernels of the other.
@@ -182,7 +183,9 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
         else hipLaunchKernelGGL((k_shade<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), 0, s, a);
         break;
     case LK_TRACE:
-        hipLaunchKernelGGL(k_trace, dim3(grid), dim3(kBlock), lds, s, a);
+        if (a.sc.use_bvh) hipLaunchKernelGGL(k_trace_bvh, dim3(grid), dim3(kBlock), lds, s, a);
+        else if (a.sc.n_generic == 0) hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(kBlock), lds, s, a);
+        else hipLaunchKernelGGL((k_trace<false>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
     default:
         if (lcg) hipLaunchKernelGGL((k_bounce<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), lds, s, a);
@@ -381,7 +384,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     size_t o_shade = al(o_xf + xforms.size() * sizeof(rtw_xform));
     size_t o_lights = al(o_shade + shade.size() * sizeof(HitRec));
     size_t o_nodes = al(o_lights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
-    size_t o_tree = al(o_nodes + std::max<size_t>(1, bvh.nodes.size()) * sizeof(BvhNode));
+    size_t o_tree = al(o_nodes + std::max<size_t>(1, bvh.wide.size()) * sizeof(BvhNode));
     size_t o_order = al(o_tree + std::max<size_t>(1, bvh.prim_order.size()) * sizeof(int32_t));
     size_t o_groups = al(o_order + std::max<size_t>(1, order.size()) * sizeof(int32_t));
     size_t o_recs = al(o_groups + std::max<size_t>(1, groups.size()) * sizeof(BruteGroup));
@@ -391,8 +394,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     memcpy(stage.data() + o_xf, xforms.data(), xforms.size() * sizeof(rtw_xform));
     if (!shade.empty()) memcpy(stage.data() + o_shade, shade.data(), shade.size() * sizeof(HitRec));
     if (!lights.empty()) memcpy(stage.data() + o_lights, lights.data(), lights.size() * sizeof(rtw_light));
-    static_assert(sizeof(BvhNode) == sizeof(rtwbvh::Node), "node layout");
-    if (!bvh.nodes.empty()) memcpy(stage.data() + o_nodes, bvh.nodes.data(), bvh.nodes.size() * sizeof(BvhNode));
+    static_assert(sizeof(BvhNode) == sizeof(rtwbvh::WideNode), "node layout");
+    if (!bvh.wide.empty()) memcpy(stage.data() + o_nodes, bvh.wide.data(), bvh.wide.size() * sizeof(BvhNode));
     if (!bvh.prim_order.empty()) memcpy(stage.data() + o_tree, bvh.prim_order.data(), bvh.prim_order.size() * sizeof(int32_t));
     if (!order.empty()) memcpy(stage.data() + o_order, order.data(), order.size() * sizeof(int32_t));
     if (!groups.empty()) memcpy(stage.data() + o_groups, groups.data(), groups.size() * sizeof(BruteGroup));
@@ -426,8 +429,19 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.has_motion = has_motion;
     sc.cam = h.camera;
     sc.pdf = h.pdf;
-    c->sc = sc;
+    // LDS per block: the traversal stacks, then as many leading (breadth-first) tree nodes as fit the budget
     c->stack_depth = use_bvh ? bvh.max_depth + 2 : 0;
+    sc.stack_depth = c->stack_depth;
+    sc.n_lds_nodes = 0;
+    if (use_bvh) {
+        size_t budget_kb = 40;
+        if (const char* e = getenv("RTW_LDS_KB")) budget_kb = (size_t)std::max(0, atoi(e));
+        const size_t stack_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
+        const size_t room = budget_kb * 1024 > stack_bytes ? budget_kb * 1024 - stack_bytes : 0;
+        sc.n_lds_nodes = (int32_t)std::min<size_t>(bvh.wide.size(), room / sizeof(BvhNode));
+    }
+    c->lds_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t) + (size_t)sc.n_lds_nodes * sizeof(BvhNode);
+    c->sc = sc;
     c->has_scene = true;
     return RTW_OK;
 }
@@ -534,7 +548,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     HIP_TRY_C(hipMemsetAsync(c->accum, 0, npix * sizeof(float4), s));
     HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), s));
 
-    const size_t lds = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
+    const size_t lds = c->lds_bytes;
     uint64_t launches = 0;
     if (P->max_depth > 0) {
         // the lanes start once the accumulators are cleared
@@ -621,6 +635,9 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
 
     unsigned long long hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     HIP_TRY_C(hipMemcpy(hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost));
+#ifdef RTW_TRACE_COUNT
+    fprintf(stderr, "[rtw] k_trace_bvh: rays %llu inner steps %llu prim tests %llu outer iterations(wave) %llu\n", hs[2 + RTW_K_TRACE], hs[6], hs[7], hs[2 + RTW_K_BOUNCE]);
+#endif
     if (stats) {
         float ms = 0.f;
         HIP_TRY_C(hipEventElapsedTime(&ms, ev_begin, ev_end));
@@ -684,7 +701,7 @@ int rtw_debug_intersect(rtw_ctx* c, const float* rays, const float* ray_time, co
     HIP_TRY_D(hipMemcpy(d_rays, rays, (size_t)n * 8 * sizeof(float), hipMemcpyHostToDevice));
     if (ray_time) { HIP_TRY_D(hipMalloc(&d_rt, (size_t)n * sizeof(float))); HIP_TRY_D(hipMemcpy(d_rt, ray_time, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); }
     if (gather_time) { HIP_TRY_D(hipMalloc(&d_gt, (size_t)n * sizeof(float))); HIP_TRY_D(hipMemcpy(d_gt, gather_time, (size_t)n * sizeof(float), hipMemcpyHostToDevice)); }
-    const size_t lds = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
+    const size_t lds = c->lds_bytes;
     hipLaunchKernelGGL(k_debug_intersect, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), lds, c->stream, c->sc, (const float*)d_rays,
                        (const float*)d_rt, (const float*)d_gt, n, d_t, d_p, (uint32_t)kBlock);
     HIP_TRY_D(hipGetLastError());

@@ -404,7 +404,8 @@ RTW_DEV void compact_store(const KArgs& A, uint32_t region, bool keep, const Pat
     if (keep) store_path(A.out, (size_t)region * A.region_cap + base + before, p);
 }
 // The trace pass of one path: radiance ray closest hit + queued shadow probe any-hit, result into the hit buffer.
-RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, uint32_t* stack, uint32_t& n_rays) {
+template <bool DUAL>
+RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, const TravMem& tm, uint32_t& n_rays) {
     NoRng ng;
     const float gt = gather_time_of(A, p.gk);
     const bool do_r = !(p.gk & kZombie);
@@ -412,18 +413,18 @@ RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, uint32_t* st
     float th = 0.f;
     int prim = -1;
     uint32_t occl = 0;
-    if (!A.sc.use_bvh && A.sc.n_generic == 0) {
+    if (DUAL) {
         // small scenes: one shared walk for both rays
         bool oc;
         traverse_dual_brute(A.sc, p.o, p.d, p.ldir, do_r, do_s, 500 * 1.0e-7f, p.ltmax, th, prim, oc);
         if (!do_r) { th = 0.f; prim = -1; }
         if (do_s) occl = (oc ? 0x80000000u : 0u) | 0x40000000u;  // bit 30: a probe was queued
     } else {
-        if (do_r) traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, stack, A.stack_stride, th, prim);
+        if (do_r) traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
         if (do_s) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
             float st;
             int sprim;
-            traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, stack, A.stack_stride, st, sprim);
+            traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, tm, st, sprim);
             occl = (sprim >= 0 ? 0x80000000u : 0u) | 0x40000000u;
         }
     }
@@ -448,6 +449,7 @@ template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     const uint32_t tid = threadIdx.x;
+    const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
     for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
@@ -511,7 +513,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             int prim;
             NoRng ng;
             const float gt = gather_time_of(A, p.gk);
-            traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, s_stack + tid, A.stack_stride, th, prim);
+            traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
             v3 so, sd, att, radiance;
             Nee nee;
             const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
@@ -540,10 +542,17 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
 
 // ------------------------------------------------------------------ k_trace
 // Only scenes without volume primitives reach this kernel, so no intersection program draws random numbers.
-__global__ void __launch_bounds__(kBlock, 8) k_trace(const KArgs A) {
+// DUAL = 1: small static scenes, both rays share one walk over the scalar-cache candidate lists (64 VGPRs, 8 waves);
+// DUAL = 0: BVH / moving-sphere scenes, one traversal per ray (the 64-byte node records want the larger budget).
+#ifndef RTW_TRACE_BVH_WAVES
+#define RTW_TRACE_BVH_WAVES 4
+#endif
+template <bool DUAL>
+__global__ void __launch_bounds__(kBlock, DUAL ? 8 : RTW_TRACE_BVH_WAVES) k_trace(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED
     const uint32_t tid = threadIdx.x;
+    const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_rays = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
     for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
@@ -554,8 +563,163 @@ __global__ void __launch_bounds__(kBlock, 8) k_trace(const KArgs A) {
         const size_t slot = (size_t)region * A.region_cap + idx;
         Path p;
         load_trace_part(A.in, slot, p);
-        trace_path(A, p, slot, s_stack + tid, n_rays);
+        trace_path<DUAL>(A, p, slot, tm, n_rays);
     }
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
+    if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
+}
+
+// ------------------------------------------------------------------ k_trace_bvh
+// BVH scenes: the number of traversal steps differs widely between the rays of a wave, so a wave that takes 64
+// rays and waits for the longest one idles most of its lanes. Here every WAVE owns a stream of 256-slot chunks
+// of the work-list and a lane that has finished its path (radiance ray, then the queued shadow probe) takes the
+// next slot of the stream as soon as kRefillIdle lanes are waiting (ballot + mbcnt ranks, no atomics).
+// Results are per-slot and independent of the order in which slots are taken.
+#ifndef RTW_REFILL_IDLE
+#define RTW_REFILL_IDLE 16
+#endif
+#ifndef RTW_LEAF_BIAS
+#define RTW_LEAF_BIAS 1
+#endif
+__global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const KArgs A) {
+    extern __shared__ uint32_t s_stack[];
+    RTW_WORKLIST_SHARED
+    const uint32_t tid = threadIdx.x;
+    const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
+    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
+    constexpr uint32_t kWaves = kBlock / 64;
+    const uint32_t stride = gridDim.x * kWaves;
+    uint32_t vc = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (tid >> 6));  // this wave's next chunk
+    uint32_t chunk_n = 0, next = 0;   // wave-uniform: size of the current chunk, slots of it already handed out
+    size_t chunk_base = 0;
+    bool exhausted = false;
+    uint32_t n_rays = 0;
+    // per-lane path and walk state
+    bool active = false;
+    size_t slot = 0;
+    v3 o = V(0.f, 0.f, 0.f), d = o, inv = o, ldir = o;
+    float ltmax = -1.f, tmin = 0.f, ray_time = 0.f, best_t = 0.f, th = 0.f, gt = 0.f;
+    int best_prim = -1, prim = -1, sp = 0;
+    uint32_t cur = kBvhDone, occl = 0;
+    bool shadow_phase = false;
+    NoRng ng;
+    const uint32_t root = A.sc.n_tree > 0 ? 0u : kBvhDone;
+#ifdef RTW_TRACE_COUNT
+    uint32_t c_inner = 0, c_prim = 0, c_outer = 0;
+#endif
+    for (;;) {
+#ifdef RTW_TRACE_COUNT
+        c_outer++;
+#endif
+        const unsigned long long idle = __ballot(!active);
+        const uint32_t n_idle = (uint32_t)__popcll(idle);
+        if (n_idle == 64u || (n_idle >= (uint32_t)RTW_REFILL_IDLE && !exhausted)) {
+            unsigned long long need = idle;
+            while (need != 0ull && !exhausted) {
+                if (next >= chunk_n) {
+                    if (vc >= wl.total_chunks) { exhausted = true; break; }
+                    uint32_t region, chunk, n_in;
+                    worklist_lookup(wl, A.n_regions, vc, region, chunk, n_in);
+                    vc += stride;
+                    chunk_base = (size_t)region * A.region_cap + (size_t)chunk * kBlock;
+                    chunk_n = min((uint32_t)kBlock, n_in - chunk * kBlock);
+                    next = 0;
+                    continue;
+                }
+                const uint32_t avail = chunk_n - next;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                const bool wants = ((need >> (tid & 63u)) & 1ull) != 0ull;
+                if (wants && rank < avail) {
+                    slot = chunk_base + next + rank;
+                    Path p;
+                    load_trace_part(A.in, slot, p);
+                    o = p.o; ldir = p.ldir; ltmax = p.ltmax; gt = gather_time_of(A, p.gk);
+                    th = 0.f; prim = -1; occl = 0;
+                    const bool do_r = !(p.gk & kZombie);
+                    if (do_r) {
+                        d = p.d; tmin = 1e-6f; best_t = 1.e27f; ray_time = p.ray_time; shadow_phase = false;
+                    } else {
+                        d = ldir; tmin = 500 * 1.0e-7f; best_t = ltmax; ray_time = 0.0f; shadow_phase = true;
+                    }
+                    inv = recip3(d);
+                    best_prim = -1; sp = 0; cur = root;
+                    if (do_r || ltmax >= 0.0f) {
+                        n_rays++;
+                        active = true;
+                    } else {
+                        A.hit_out[slot] = make_uint2(0u, 0u);  // a zombie without a probe (does not occur; kept total)
+                    }
+                }
+                next += min((uint32_t)__popcll(need), avail);
+                need = __ballot(!active);
+            }
+            if (__ballot(active) == 0ull) break;
+        }
+        // One kind of step at a time, chosen by majority: while the lanes standing at inner nodes are not
+        // outnumbered they keep stepping down (a tight loop); then the lanes standing at a leaf test one primitive.
+        // Executing only the majority's branch keeps most lanes busy whatever the mix; the minority waits and grows
+        // until it is the majority.
+        const uint32_t n_act = (uint32_t)__popcll(__ballot(active));
+        bool at_inner = active && (cur >> 30) == 0u;
+        for (;;) {
+            const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
+            if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_act - n_in) break;
+            if (at_inner) {
+                cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
+                at_inner = (cur >> 30) == 0u;
+#ifdef RTW_TRACE_COUNT
+                c_inner++;
+#endif
+            }
+        }
+        const bool at_leaf = active && !at_inner && cur != kBvhDone;
+        if (at_leaf) {
+            const uint32_t first = cur & 0x3fffffffu, cnt = cur >> 30;
+#ifdef RTW_TRACE_COUNT
+            c_prim++;
+#endif
+            const int pi = load_i32(A.sc.tree_prims + first);
+            const rtw_prim pr = load_prim(A.sc, pi);
+            v3 po, pd, mt;
+            object_ray(A.sc, pr, o, d, ray_time, po, pd, mt);
+            v3 pinv = inv;
+            if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
+            float t;
+            bool stop = false;
+            if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gt, ng, t)) {
+                // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
+                if (t < best_t || (!shadow_phase && t == best_t && best_prim >= 0 && pi < best_prim)) {
+                    best_t = t; best_prim = pi;
+                    stop = shadow_phase;
+                }
+            }
+            cur = stop ? kBvhDone : (cnt > 1u ? ((first + 1u) | ((cnt - 1u) << 30)) : bvh_pop(tm, sp));
+        }
+        if (active) {
+            if (cur == kBvhDone) {
+                // this ray is done
+                if (!shadow_phase) {
+                    th = best_t; prim = best_prim;
+                    if (ltmax >= 0.0f) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
+                        d = ldir; inv = recip3(d); tmin = 500 * 1.0e-7f; best_t = ltmax; ray_time = 0.0f;
+                        best_prim = -1; sp = 0; cur = root; shadow_phase = true;
+                        n_rays++;
+                    } else {
+                        A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1));
+                        active = false;
+                    }
+                } else {
+                    occl = (best_prim >= 0 ? 0x80000000u : 0u) | 0x40000000u;  // bit 30: a probe was queued
+                    A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
+                    active = false;
+                }
+            }
+        }
+    }
+#ifdef RTW_TRACE_COUNT
+    for (int off = 32; off > 0; off >>= 1) { c_inner += __shfl_down(c_inner, off); c_prim += __shfl_down(c_prim, off); }
+    if ((tid & 63u) == 0) { atomicAdd(&A.stats[6], (unsigned long long)c_inner); atomicAdd(&A.stats[7], (unsigned long long)c_prim); atomicAdd(&A.stats[2 + RTW_K_BOUNCE], (unsigned long long)c_outer); }
+#endif
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
@@ -626,7 +790,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
     extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED
     const uint32_t tid = threadIdx.x;
-    uint32_t* my_stack = s_stack + tid;
+    const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
     for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
@@ -645,7 +809,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
             if (p.ltmax >= 0.0f) {  // a probe queued by k_shade: resolve it here
                 float st;
                 int sprim;
-                traverse<Rng<KIND>, true, false>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, g, my_stack, A.stack_stride, st, sprim);
+                traverse<Rng<KIND>, true, false>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, g, tm, st, sprim);
                 if (sprim < 0) p.L = vadd(p.L, p.c);
                 p.ltmax = -1.0f;
             }
@@ -659,7 +823,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                 for (uint32_t it = 0; it < A.n_iter; it++) {
                     float t;
                     int prim;
-                    traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, g, my_stack, A.stack_stride, t, prim);
+                    traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, g, tm, t, prim);
                     v3 so, sd, att, radiance;
                     Nee nee;
                     const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, t, prim, so, sd, att, radiance, nee);
@@ -667,7 +831,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                     if (nee.has) {
                         float st;
                         int sprim;
-                        traverse<Rng<KIND>, true, false>(A.sc, so, nee.dir, nee.tmin, nee.tmax, 0.0f, gt, g, my_stack, A.stack_stride, st, sprim);
+                        traverse<Rng<KIND>, true, false>(A.sc, so, nee.dir, nee.tmin, nee.tmax, 0.0f, gt, g, tm, st, sprim);
                         n_shadow++;
                         if (sprim < 0) radiance = vadd(radiance, nee.rad);
                     }
@@ -709,6 +873,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_intersect(const DScene sc, con
                                                            const float* __restrict__ gather_time, int n, float* __restrict__ out_t,
                                                            int32_t* __restrict__ out_prim, uint32_t stack_stride) {
     extern __shared__ uint32_t s_stack[];
+    const TravMem tm = trav_mem(sc, s_stack, stack_stride, threadIdx.x);  // before the early exit: it holds a barrier
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float* r = rays + 8 * (size_t)i;
@@ -716,7 +881,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_intersect(const DScene sc, con
     float t;
     int prim;
     traverse<NoRng, false, true>(sc, V(r[0], r[1], r[2]), V(r[3], r[4], r[5]), r[6], r[7], ray_time ? ray_time[i] : 0.f,
-                                 gather_time ? gather_time[i] : 0.f, g, s_stack + threadIdx.x, stack_stride, t, prim);
+                                 gather_time ? gather_time[i] : 0.f, g, tm, t, prim);
     out_t[i] = t;
     out_prim[i] = prim;
 }

@@ -68,3 +68,23 @@ def intersect(blob, rays, ray_time=None, gather_time=None):
     if rc != 0:
         raise RuntimeError(f"rtwo_intersect failed: {rc}")
     return t, prim
+
+
+def cluttered_cornell(w, h, n_extra=40, seed=7):
+    """Cornell box (reference scene 0) with n_extra small spheres added: > 24 primitives, so the HIP library walks
+    its BVH, and the scene keeps its rect light, so queued shadow probes go through the tree as well. Synthetic
+    (not a reference scene): exercises tree + light sampling + transforms together."""
+    import numpy as np
+    from raytracing_weekend_amd import abi
+    parts = abi.parse_scene(abi.build_scene(0, w, h))
+    prims = list(parts["prims"])
+    n_mat = len(parts["materials"])
+    rs = np.random.RandomState(seed)
+    for i in range(n_extra):
+        pr = abi.Prim(type=abi.PRIM_SPHERE, material=int(rs.randint(0, n_mat)), xform=0, flip=0)
+        r = float(rs.uniform(12.0, 30.0))
+        pr.p[0], pr.p[1], pr.p[2], pr.p[3] = (float(rs.uniform(60, 495)), float(rs.uniform(40, 500)), float(rs.uniform(60, 495)), r)
+        prims.append(pr)
+    parts = dict(parts)
+    parts["prims"] = prims
+    return abi.assemble_scene(parts)

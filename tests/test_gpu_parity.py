@@ -73,6 +73,21 @@ def test_matches_oracle(gpu, scene, w, h, spp, depth, rng):
     check(img, ref, st, st_ref)
 
 
+@pytest.mark.parametrize("rng", [abi.RTW_RNG_PHILOX, abi.RTW_RNG_TEA_LCG])
+def test_tree_scene_with_light_matches_oracle(gpu, rng):
+    """Cornell box + 40 spheres: the BVH walk (refilling k_trace_bvh), queued shadow probes through the tree,
+    the transformed boxes inside the tree."""
+    w, h = 144, 96
+    blob = oracle.cluttered_cornell(w, h)
+    gpu.upload_scene(blob)
+    for spp, depth in ((6, 50), (3, 2)):
+        p = abi.make_params(w, h, spp, depth, rng_kind=rng)
+        img, st = gpu.render(p)
+        ref, st_ref = oracle.render(blob, p, threads=16)
+        assert st_ref.shadow_rays > 0
+        check(img, ref, st, st_ref)
+
+
 def test_edge_cases(gpu):
     blob = abi.build_scene(0, 8, 8)
     gpu.upload_scene(blob)

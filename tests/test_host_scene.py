@@ -101,3 +101,12 @@ def test_host_builder_reproduces_fixture_blobs():
         z = np.load(os.path.join(GOLD, name))
         scene, w, h = (int(v) for v in z["meta"][:3])
         assert abi.build_scene(scene, w, h) == z["blob"].tobytes(), name
+
+
+def test_scene_blob_parse_assemble_roundtrip():
+    for scene in (0, 1, 3):
+        blob = abi.build_scene(scene, 40, 30)
+        assert abi.assemble_scene(abi.parse_scene(blob)) == blob
+    import oracle
+    big = oracle.cluttered_cornell(40, 30, n_extra=12)
+    assert abi.parse_scene(big)["header"].n_prims == abi.parse_scene(abi.build_scene(0, 40, 30))["header"].n_prims + 12
