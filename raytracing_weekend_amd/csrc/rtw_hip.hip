@@ -434,7 +434,9 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.stack_depth = c->stack_depth;
     sc.n_lds_nodes = 0;
     if (use_bvh) {
-        size_t budget_kb = 40;
+        // Measured on scene 1 (13 levels, 318 nodes): occupancy is worth more than LDS-resident nodes - 16 KB
+        // (the stacks plus the top few levels) beats 22 / 30 / 36 KB by 10-25 %; the work-list statics add 9.3 KB.
+        size_t budget_kb = 16;
         if (const char* e = getenv("RTW_LDS_KB")) budget_kb = (size_t)std::max(0, atoi(e));
         const size_t stack_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
         const size_t room = budget_kb * 1024 > stack_bytes ? budget_kb * 1024 - stack_bytes : 0;
@@ -472,9 +474,25 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     S = std::min<size_t>(S, (size_t)P->spp);
     while (S > 1 && npix * S > 0xfffffff0ull) S--;
     const size_t paths_max = npix * S;
-    // region capacity: a multiple of 256 paths, at least 16384, large enough that <= kMaxRegions regions cover the pool
-    size_t region_cap = std::max<size_t>(kMinRegionCap, (((paths_max + kMaxRegions - 1) / kMaxRegions) + kBlock - 1) / kBlock * kBlock);
-    const uint32_t regions_max = (uint32_t)((paths_max + region_cap - 1) / region_cap);
+    // Persistent compacting grid: G workgroups (8 per CU when a lane has the GPU to itself, 4 when two lanes share it).
+    // Output region b belongs to workgroup b, which is handed every G-th 256-path chunk of its input: at most
+    // ceil(chunks / G) + 1 chunks (the work list of a later launch has up to one partial chunk per region more than
+    // the first), so a region of (ceil(chunks / G) + 2) * 256 slots cannot overflow.
+    const size_t n_batches = ((size_t)P->spp + S - 1) / S;
+    const int n_lanes = (int)std::min<size_t>((size_t)want_lanes, std::max<size_t>(n_batches, 1));
+    uint32_t grid_mult = n_lanes > 1 ? 4u : 8u;
+    if (const char* e = getenv("RTW_GRID_MULT")) grid_mult = (uint32_t)std::max(1, atoi(e));
+    auto grid_for = [&](size_t paths) {
+        const size_t chunks = (paths + kBlock - 1) / kBlock;
+        return (uint32_t)std::min<size_t>(std::min<size_t>(chunks, (size_t)c->n_cu * grid_mult), (size_t)kMaxRegions);
+    };
+    auto cap_for = [&](size_t paths) {
+        const size_t chunks = (paths + kBlock - 1) / kBlock;
+        const size_t g = grid_for(paths);
+        return ((chunks + g - 1) / g + 2) * (size_t)kBlock;
+    };
+    const uint32_t regions_max = grid_for(paths_max);
+    const size_t region_cap_max = cap_for(paths_max);
     bool split_first = false;
     // Launch schedule of one batch. Wide bounces: one k_shade + one k_trace per bounce (split pipeline; scenes
     // whose intersection programs draw random numbers keep trace and shade fused in k_bounce instead).
@@ -507,9 +525,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         split_first = split;
     }
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
-    const size_t n_batches = ((size_t)P->spp + S - 1) / S;
-    const int n_lanes = (int)std::min<size_t>((size_t)want_lanes, std::max<size_t>(n_batches, 1));
-    int rc = ensure_pool(c, n_lanes, (size_t)regions_max * region_cap, npix, cnt_words);
+    int rc = ensure_pool(c, n_lanes, (size_t)regions_max * region_cap_max, npix, cnt_words);
     if (rc) return rc;
     hipEvent_t ev_begin = nullptr, ev_end = nullptr;
     HIP_TRY(c, hipEventCreate(&ev_begin));
@@ -562,7 +578,8 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             hipStream_t ls = L.st;
             const size_t Sb = std::min(S, (size_t)P->spp - s0);
             const size_t paths = npix * Sb;
-            const uint32_t regions = (uint32_t)((paths + region_cap - 1) / region_cap);
+            const uint32_t regions = grid_for(paths);
+            const size_t region_cap = cap_for(paths);
             // this lane's pool is free again once the resolve of its previous batch has run on the main stream
             HIP_TRY_C(hipStreamWaitEvent(ls, bi < (size_t)n_lanes ? ev_ready : L.ev_free, 0));
             HIP_TRY_C(hipMemsetAsync(L.cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), ls));
@@ -585,11 +602,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             a.stack_stride = kBlock;
             a.region_cap = (uint32_t)region_cap;
             a.trace_first = split_first ? 1u : 0u;
-            const uint32_t n_chunks = (uint32_t)((paths + kBlock - 1) / kBlock);
-            // persistent grids: 8 workgroups per CU when a lane has the GPU to itself, 4 when two lanes share it
-            uint32_t grid_mult = n_lanes > 1 ? 4u : 8u;
-            if (const char* e = getenv("RTW_GRID_MULT")) grid_mult = (uint32_t)std::max(1, atoi(e));
-            const int grid = (int)std::min<uint32_t>(n_chunks, (uint32_t)c->n_cu * grid_mult);
+            const int grid = (int)regions;  // every compacting launch uses exactly this grid: workgroup b owns region b
             // k_first fills buffer 0 (and the hit buffer); every compacting launch then flips the buffers
             int cur = 0;
             size_t ci = 0;  // index of the region-counter row describing buffer `cur`

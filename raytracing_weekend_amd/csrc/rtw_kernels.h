@@ -31,8 +31,7 @@ using namespace rtwdev;
 #define RTW_MIN_WAVES 1
 #endif
 constexpr int kBlock = 256;                       // 4 wave64 per workgroup
-constexpr uint32_t kMinRegionCap = 64 * kBlock;   // a region holds at least 64 chunks of 256 paths
-constexpr uint32_t kMaxRegions = 2048;            // region counters scanned in LDS by every workgroup
+constexpr uint32_t kMaxRegions = 2048;            // region counters scanned in LDS by every workgroup (>= the compacting grid)
 constexpr uint32_t kZombie = 0x80000000u;
 
 struct PathBuf {
@@ -46,7 +45,7 @@ struct KArgs {
     uint2* hit_out;             // hit records of the OUTPUT slots (k_trace: of the slots it reads)
     float4* lbuf;               // per path id: final radiance of the sample
     const uint32_t* cnt_in;     // live paths per region (input)
-    uint32_t* cnt_out;          // live paths per region (output), zeroed per batch
+    uint32_t* cnt_out;          // live paths per region (output): region b is written by workgroup b alone
     unsigned long long* stats;  // [0] segments, [1] shadow probes, [2 + kind] segments per kernel kind
     uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, trace_first;
     uint32_t row_stride;        // >= 1: local row l of the shard is image row row0 + l*row_stride
@@ -100,25 +99,23 @@ RTW_DEV void store_path(const PathBuf& B, size_t s, const Path& p) {
 // counters into an LDS prefix array once, then strides over the virtual chunk ids: no empty
 // iterations, perfect balance, and a launch with nothing alive costs one scan.
 struct WorkList {
-    uint32_t* pref;  // [kMaxRegions+1] exclusive prefix of chunk counts
-    uint32_t* raw;   // [kMaxRegions]
+    uint32_t* pref;  // [kMaxRegions+1]: (exclusive prefix of chunk counts) << 8 | (live paths of the region) & 255
     uint32_t total_chunks;
 };
 #define RTW_WORKLIST_SHARED                        \
     __shared__ uint32_t s_pref[kMaxRegions + 1];   \
-    __shared__ uint32_t s_raw[kMaxRegions];        \
     __shared__ uint32_t s_part[kBlock];
 
-RTW_DEV WorkList worklist_init(const uint32_t* cnt_in, uint32_t n_regions, uint32_t* s_pref, uint32_t* s_raw, uint32_t* s_part) {
+RTW_DEV WorkList worklist_init(const uint32_t* cnt_in, uint32_t n_regions, uint32_t* s_pref, uint32_t* s_part) {
     const uint32_t tid = threadIdx.x;
     constexpr uint32_t kPer = kMaxRegions / kBlock;
-    uint32_t loc[kPer];
+    uint32_t loc[kPer], low[kPer];
     uint32_t sum = 0;
 #pragma unroll
     for (uint32_t j = 0; j < kPer; j++) {
         const uint32_t r = tid * kPer + j;
         const uint32_t raw = r < n_regions ? cnt_in[r] : 0u;
-        s_raw[r] = raw;
+        low[j] = raw & 255u;
         loc[j] = sum;
         sum += (raw + kBlock - 1) / kBlock;
     }
@@ -132,22 +129,26 @@ RTW_DEV WorkList worklist_init(const uint32_t* cnt_in, uint32_t n_regions, uint3
     }
     const uint32_t excl = s_part[tid] - sum;
 #pragma unroll
-    for (uint32_t j = 0; j < kPer; j++) s_pref[tid * kPer + j] = excl + loc[j];
-    if (tid == kBlock - 1) s_pref[kMaxRegions] = s_part[tid];
+    for (uint32_t j = 0; j < kPer; j++) s_pref[tid * kPer + j] = ((excl + loc[j]) << 8) | low[j];
+    if (tid == kBlock - 1) s_pref[kMaxRegions] = s_part[tid] << 8;
     __syncthreads();
     WorkList w;
-    w.pref = s_pref; w.raw = s_raw; w.total_chunks = s_pref[kMaxRegions];
+    w.pref = s_pref; w.total_chunks = s_pref[kMaxRegions] >> 8;
     return w;
 }
-RTW_DEV void worklist_lookup(const WorkList& w, uint32_t n_regions, uint32_t vc, uint32_t& region, uint32_t& chunk, uint32_t& n_in) {
-    uint32_t lo = 0, hi = n_regions;  // largest r with pref[r] <= vc
+// virtual chunk id -> (region, chunk within the region, number of live paths in that chunk: 256 but for a region's last)
+RTW_DEV void worklist_lookup(const WorkList& w, uint32_t n_regions, uint32_t vc, uint32_t& region, uint32_t& chunk, uint32_t& n_valid) {
+    uint32_t lo = 0, hi = n_regions;  // largest r with prefix[r] <= vc
     while (hi - lo > 1) {
         const uint32_t mid = (lo + hi) >> 1;
-        if (w.pref[mid] <= vc) lo = mid; else hi = mid;
+        if ((w.pref[mid] >> 8) <= vc) lo = mid; else hi = mid;
     }
+    const uint32_t e = w.pref[lo];
+    const uint32_t n_chunks = (w.pref[lo + 1] >> 8) - (e >> 8);
+    const uint32_t rem = e & 255u;
     region = lo;
-    chunk = vc - w.pref[lo];
-    n_in = w.raw[lo];
+    chunk = vc - (e >> 8);
+    n_valid = (chunk + 1u < n_chunks || rem == 0u) ? kBlock : rem;
 }
 
 struct NoRng {
@@ -187,7 +188,11 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     if (hr.mat_type != RTW_MAT_DIFFUSE_LIGHT && hr.mat_type != RTW_MAT_NORMAL) g.warm();
     v3 hp, hn;
     hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
+#ifdef RTW_ABLATE_LAMBERT  // timing experiment only (wrong images): every surface shades as lambertian
+    const int mtype = hr.mat_type == RTW_MAT_DIFFUSE_LIGHT ? RTW_MAT_DIFFUSE_LIGHT : RTW_MAT_LAMBERTIAN;
+#else
     const int mtype = hr.mat_type;
+#endif
     const float mparam = hr.param;
     const v3 tex = V(hr.r, hr.g, hr.b);
     int ev;
@@ -394,14 +399,26 @@ RTW_DEV void finish_path(const KArgs& A, uint32_t path_id, v3 L) {
     A.lbuf[path_id] = make_float4(lx, ly, lz, 0.f);
 }
 // wave64 ballot + popcount prefix; one atomic per wave reserves its slice of the region's output
-RTW_DEV void compact_store(const KArgs& A, uint32_t region, bool keep, const Path& p) {
+// Stream compaction without global atomics: output region b belongs to workgroup b, whose four waves share a
+// cursor in LDS (agent-scope atomics are resolved beyond the XCD's L2 on this part, ~0.4 us each and serialised per
+// address). The host sizes a region for the most paths one workgroup of the persistent grid can be handed.
+#define RTW_CURSOR_SHARED __shared__ uint32_t s_cursor;
+RTW_DEV void cursor_init(uint32_t* s_cursor) {
+    if (threadIdx.x == 0) *s_cursor = 0u;
+    __syncthreads();
+}
+RTW_DEV void cursor_publish(const KArgs& A, uint32_t* s_cursor) {
+    __syncthreads();
+    if (threadIdx.x == 0) A.cnt_out[blockIdx.x] = *s_cursor;
+}
+RTW_DEV void compact_store(const KArgs& A, uint32_t* s_cursor, bool keep, const Path& p) {
     const unsigned long long ballot = __ballot(keep);
     if (!ballot) return;
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
     uint32_t base = 0;
-    if ((threadIdx.x & 63u) == 0) base = atomicAdd(&A.cnt_out[region], (uint32_t)__popcll(ballot));
+    if ((threadIdx.x & 63u) == 0) base = atomicAdd(s_cursor, (uint32_t)__popcll(ballot));
     base = __builtin_amdgcn_readfirstlane(base);
-    if (keep) store_path(A.out, (size_t)region * A.region_cap + base + before, p);
+    if (keep) store_path(A.out, (size_t)blockIdx.x * A.region_cap + base + before, p);
 }
 // The trace pass of one path: radiance ray closest hit + queued shadow probe any-hit, result into the hit buffer.
 template <bool DUAL>
@@ -448,13 +465,14 @@ RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow, int 
 template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
+    RTW_CURSOR_SHARED
     const uint32_t tid = threadIdx.x;
+    cursor_init(&s_cursor);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
     for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
         const uint32_t path_id = vc * kBlock + tid;
-        const uint32_t path_region = (vc * kBlock) / A.region_cap;  // region_cap is a multiple of the chunk size
         bool keep = false;
         Path p;
         p.gk = 0; p.ltmax = -1.f;
@@ -535,8 +553,9 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             }
         }
         }
-        compact_store(A, path_region, keep, p);
+        compact_store(A, &s_cursor, keep, p);
     }
+    cursor_publish(A, &s_cursor);
     flush_stats(A, n_seg, n_shadow, RTW_K_FIRST);
 }
 
@@ -554,12 +573,12 @@ __global__ void __launch_bounds__(kBlock, DUAL ? 8 : RTW_TRACE_BVH_WAVES) k_trac
     const uint32_t tid = threadIdx.x;
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_rays = 0;
-    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
+    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
     for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
-        uint32_t region, chunk, n_in;
-        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_in);
+        uint32_t region, chunk, n_valid;
+        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
         const uint32_t idx = chunk * kBlock + tid;
-        if (idx >= n_in) continue;
+        if (tid >= n_valid) continue;
         const size_t slot = (size_t)region * A.region_cap + idx;
         Path p;
         load_trace_part(A.in, slot, p);
@@ -586,7 +605,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
     RTW_WORKLIST_SHARED
     const uint32_t tid = threadIdx.x;
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
-    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
+    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
     constexpr uint32_t kWaves = kBlock / 64;
     const uint32_t stride = gridDim.x * kWaves;
     uint32_t vc = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (tid >> 6));  // this wave's next chunk
@@ -618,11 +637,11 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
             while (need != 0ull && !exhausted) {
                 if (next >= chunk_n) {
                     if (vc >= wl.total_chunks) { exhausted = true; break; }
-                    uint32_t region, chunk, n_in;
-                    worklist_lookup(wl, A.n_regions, vc, region, chunk, n_in);
+                    uint32_t region, chunk, n_valid;
+                    worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
                     vc += stride;
                     chunk_base = (size_t)region * A.region_cap + (size_t)chunk * kBlock;
-                    chunk_n = min((uint32_t)kBlock, n_in - chunk * kBlock);
+                    chunk_n = n_valid;
                     next = 0;
                     continue;
                 }
@@ -731,14 +750,16 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
 template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A) {
     RTW_WORKLIST_SHARED
+    RTW_CURSOR_SHARED
     const uint32_t tid = threadIdx.x;
+    cursor_init(&s_cursor);
     uint32_t n_seg = 0, n_shadow = 0;
-    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
+    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
     for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
-        uint32_t region, chunk, n_in;
-        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_in);
+        uint32_t region, chunk, n_valid;
+        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
         const uint32_t idx = chunk * kBlock + tid;
-        const bool valid = idx < n_in;
+        const bool valid = tid < n_valid;
         bool keep = false;
         Path p;
         p.gk = 0; p.ltmax = -1.f;
@@ -779,8 +800,9 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
                 }
             }
         }
-        compact_store(A, region, keep, p);
+        compact_store(A, &s_cursor, keep, p);
     }
+    cursor_publish(A, &s_cursor);
     flush_stats(A, n_seg, n_shadow, RTW_K_SHADE);
 }
 
@@ -789,15 +811,17 @@ template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED
+    RTW_CURSOR_SHARED
     const uint32_t tid = threadIdx.x;
+    cursor_init(&s_cursor);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
-    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_raw, s_part);
+    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
     for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
-        uint32_t region, chunk, n_in;
-        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_in);
+        uint32_t region, chunk, n_valid;
+        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
         const uint32_t idx = chunk * kBlock + tid;
-        const bool valid = idx < n_in;
+        const bool valid = tid < n_valid;
         bool keep = false;
         Path p;
         p.gk = 0; p.ltmax = -1.f;
@@ -845,8 +869,9 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                 else finish_path(A, path_id_of<KIND>(A, p), p.L);
             }
         }
-        compact_store(A, region, keep, p);
+        compact_store(A, &s_cursor, keep, p);
     }
+    cursor_publish(A, &s_cursor);
     flush_stats(A, n_seg, n_shadow, RTW_K_BOUNCE);
 }
 
