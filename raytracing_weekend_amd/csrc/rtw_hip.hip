@@ -148,7 +148,7 @@ int ensure_pool(rtw_ctx* c, int n_lanes, size_t paths, size_t npix, size_t cnt_w
         HIP_TRY(c, hipMalloc(&c->accum, npix * sizeof(float4)));
         c->accum_pix = npix;
     }
-    if (!c->d_stats) HIP_TRY(c, hipMalloc(&c->d_stats, 8 * sizeof(unsigned long long)));
+    if (!c->d_stats) HIP_TRY(c, hipMalloc(&c->d_stats, kStatRows * 8 * sizeof(unsigned long long)));
     return RTW_OK;
 }
 
@@ -562,7 +562,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
 
     HIP_TRY_C(hipEventRecord(ev_begin, s));
     HIP_TRY_C(hipMemsetAsync(c->accum, 0, npix * sizeof(float4), s));
-    HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, 8 * sizeof(unsigned long long), s));
+    HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, kStatRows * 8 * sizeof(unsigned long long), s));
 
     const size_t lds = c->lds_bytes;
     uint64_t launches = 0;
@@ -647,7 +647,12 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     HIP_TRY_C(hipEventSynchronize(ev_end));
 
     unsigned long long hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    HIP_TRY_C(hipMemcpy(hs, c->d_stats, sizeof hs, hipMemcpyDeviceToHost));
+    {
+        unsigned long long rows[kStatRows * 8];
+        HIP_TRY_C(hipMemcpy(rows, c->d_stats, sizeof rows, hipMemcpyDeviceToHost));
+        for (uint32_t r = 0; r < kStatRows; r++)
+            for (int k = 0; k < 8; k++) hs[k] += rows[r * 8 + k];
+    }
 #ifdef RTW_TRACE_COUNT
     fprintf(stderr, "[rtw] k_trace_bvh: rays %llu inner steps %llu prim tests %llu outer iterations(wave) %llu\n", hs[2 + RTW_K_TRACE], hs[6], hs[7], hs[2 + RTW_K_BOUNCE]);
 #endif

@@ -402,21 +402,40 @@ RTW_DEV void finish_path(const KArgs& A, uint32_t path_id, v3 L) {
 // Stream compaction without global atomics: output region b belongs to workgroup b, whose four waves share a
 // cursor in LDS (agent-scope atomics are resolved beyond the XCD's L2 on this part, ~0.4 us each and serialised per
 // address). The host sizes a region for the most paths one workgroup of the persistent grid can be handed.
-#define RTW_CURSOR_SHARED __shared__ uint32_t s_cursor;
+// s_cursor[0]: the output cursor; [1], [2]: this workgroup's segment / shadow-ray counts. The render statistics live in
+// kStatRows rows of 8 counters (row = workgroup & 63, summed by the host) so that the one global atomic per workgroup
+// and counter does not queue behind every other workgroup's on a single address.
+constexpr uint32_t kStatRows = 64;
+#define RTW_CURSOR_SHARED __shared__ uint32_t s_cursor[3];
 RTW_DEV void cursor_init(uint32_t* s_cursor) {
-    if (threadIdx.x == 0) *s_cursor = 0u;
+    if (threadIdx.x < 3) s_cursor[threadIdx.x] = 0u;
     __syncthreads();
 }
-RTW_DEV void cursor_publish(const KArgs& A, uint32_t* s_cursor) {
+RTW_DEV unsigned long long* stat_row(const KArgs& A) { return A.stats + (size_t)(blockIdx.x & (kStatRows - 1u)) * 8u; }
+RTW_DEV void cursor_publish(const KArgs& A, uint32_t* s_cursor, uint32_t n_seg, uint32_t n_shadow, int kind) {
+    for (int off = 32; off > 0; off >>= 1) {
+        n_seg += __shfl_down(n_seg, off);
+        n_shadow += __shfl_down(n_shadow, off);
+    }
+    if ((threadIdx.x & 63u) == 0 && (n_seg | n_shadow)) {
+        atomicAdd(&s_cursor[1], n_seg);
+        atomicAdd(&s_cursor[2], n_shadow);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) A.cnt_out[blockIdx.x] = *s_cursor;
+    if (threadIdx.x == 0) {
+        A.cnt_out[blockIdx.x] = s_cursor[0];
+        const uint32_t a = s_cursor[1], b = s_cursor[2];
+        unsigned long long* row = stat_row(A);
+        if (a) { atomicAdd(&row[0], (unsigned long long)a); atomicAdd(&row[2 + kind], (unsigned long long)a); }
+        if (b) atomicAdd(&row[1], (unsigned long long)b);
+    }
 }
 RTW_DEV void compact_store(const KArgs& A, uint32_t* s_cursor, bool keep, const Path& p) {
     const unsigned long long ballot = __ballot(keep);
     if (!ballot) return;
     const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(ballot >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)ballot, 0u));
     uint32_t base = 0;
-    if ((threadIdx.x & 63u) == 0) base = atomicAdd(s_cursor, (uint32_t)__popcll(ballot));
+    if ((threadIdx.x & 63u) == 0) base = atomicAdd(&s_cursor[0], (uint32_t)__popcll(ballot));
     base = __builtin_amdgcn_readfirstlane(base);
     if (keep) store_path(A.out, (size_t)blockIdx.x * A.region_cap + base + before, p);
 }
@@ -449,25 +468,13 @@ RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, const TravMe
     A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
 }
 
-RTW_DEV void flush_stats(const KArgs& A, uint32_t n_seg, uint32_t n_shadow, int kind) {
-    for (int off = 32; off > 0; off >>= 1) {
-        n_seg += __shfl_down(n_seg, off);
-        n_shadow += __shfl_down(n_shadow, off);
-    }
-    if ((threadIdx.x & 63u) == 0 && (n_seg | n_shadow)) {
-        atomicAdd(&A.stats[0], (unsigned long long)n_seg);
-        atomicAdd(&A.stats[1], (unsigned long long)n_shadow);
-        atomicAdd(&A.stats[2 + kind], (unsigned long long)n_seg);
-    }
-}
-
 // ------------------------------------------------------------------ k_first
 template <int KIND>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_CURSOR_SHARED
     const uint32_t tid = threadIdx.x;
-    cursor_init(&s_cursor);
+    cursor_init(s_cursor);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
@@ -553,10 +560,9 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             }
         }
         }
-        compact_store(A, &s_cursor, keep, p);
+        compact_store(A, s_cursor, keep, p);
     }
-    cursor_publish(A, &s_cursor);
-    flush_stats(A, n_seg, n_shadow, RTW_K_FIRST);
+    cursor_publish(A, s_cursor, n_seg, n_shadow, RTW_K_FIRST);
 }
 
 // ------------------------------------------------------------------ k_trace
@@ -574,18 +580,21 @@ __global__ void __launch_bounds__(kBlock, DUAL ? 8 : RTW_TRACE_BVH_WAVES) k_trac
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_rays = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
-    for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
-        uint32_t region, chunk, n_valid;
-        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
-        const uint32_t idx = chunk * kBlock + tid;
-        if (tid >= n_valid) continue;
-        const size_t slot = (size_t)region * A.region_cap + idx;
+    // the work-list lookup of the next chunk (a dependent chain of LDS reads) is issued behind this chunk's loads
+    uint32_t vc = blockIdx.x, region = 0, chunk = 0, n_valid = 0;
+    if (vc < wl.total_chunks) worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
+    while (vc < wl.total_chunks) {
+        const bool valid = tid < n_valid;
+        const size_t slot = (size_t)region * A.region_cap + chunk * kBlock + tid;
         Path p;
-        load_trace_part(A.in, slot, p);
-        trace_path<DUAL>(A, p, slot, tm, n_rays);
+        p.gk = 0; p.ltmax = -1.f;
+        if (valid) load_trace_part(A.in, slot, p);
+        vc += gridDim.x;
+        if (vc < wl.total_chunks) worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
+        if (valid) trace_path<DUAL>(A, p, slot, tm, n_rays);
     }
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
-    if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
+    if ((tid & 63u) == 0 && n_rays) atomicAdd(&stat_row(A)[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
 
 // ------------------------------------------------------------------ k_trace_bvh
@@ -740,7 +749,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
     if ((tid & 63u) == 0) { atomicAdd(&A.stats[6], (unsigned long long)c_inner); atomicAdd(&A.stats[7], (unsigned long long)c_prim); atomicAdd(&A.stats[2 + RTW_K_BOUNCE], (unsigned long long)c_outer); }
 #endif
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
-    if ((tid & 63u) == 0 && n_rays) atomicAdd(&A.stats[2 + RTW_K_TRACE], (unsigned long long)n_rays);
+    if ((tid & 63u) == 0 && n_rays) atomicAdd(&stat_row(A)[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
 
 // ------------------------------------------------------------------ k_shade
@@ -752,21 +761,26 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
     RTW_WORKLIST_SHARED
     RTW_CURSOR_SHARED
     const uint32_t tid = threadIdx.x;
-    cursor_init(&s_cursor);
+    cursor_init(s_cursor);
     uint32_t n_seg = 0, n_shadow = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
-    for (uint32_t vc = blockIdx.x; vc < wl.total_chunks; vc += gridDim.x) {
-        uint32_t region, chunk, n_valid;
-        worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
-        const uint32_t idx = chunk * kBlock + tid;
+    // the work-list lookup of the next chunk (a dependent chain of LDS reads) is issued behind this chunk's loads
+    uint32_t vc = blockIdx.x, region = 0, chunk = 0, n_valid = 0;
+    if (vc < wl.total_chunks) worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
+    while (vc < wl.total_chunks) {
         const bool valid = tid < n_valid;
         bool keep = false;
         Path p;
         p.gk = 0; p.ltmax = -1.f;
+        uint2 h = make_uint2(0u, 0u);
         if (valid) {
-            const size_t slot = (size_t)region * A.region_cap + idx;
+            const size_t slot = (size_t)region * A.region_cap + chunk * kBlock + tid;
             load_shade_part(A.in, slot, p);
-            const uint2 h = A.hit[slot];
+            h = A.hit[slot];
+        }
+        vc += gridDim.x;
+        if (vc < wl.total_chunks) worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
+        if (valid) {
             // the light sample queued by the previous bounce (closehit.cu:103-113), now that its probe is back
             if ((h.y & 0xc0000000u) == 0x40000000u) p.L = vadd(p.L, p.c);
             if (p.gk & kZombie) {
@@ -800,10 +814,9 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
                 }
             }
         }
-        compact_store(A, &s_cursor, keep, p);
+        compact_store(A, s_cursor, keep, p);
     }
-    cursor_publish(A, &s_cursor);
-    flush_stats(A, n_seg, n_shadow, RTW_K_SHADE);
+    cursor_publish(A, s_cursor, n_seg, n_shadow, RTW_K_SHADE);
 }
 
 // ------------------------------------------------------------------ k_bounce (fused)
@@ -813,7 +826,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
     RTW_WORKLIST_SHARED
     RTW_CURSOR_SHARED
     const uint32_t tid = threadIdx.x;
-    cursor_init(&s_cursor);
+    cursor_init(s_cursor);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
@@ -869,10 +882,9 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                 else finish_path(A, path_id_of<KIND>(A, p), p.L);
             }
         }
-        compact_store(A, &s_cursor, keep, p);
+        compact_store(A, s_cursor, keep, p);
     }
-    cursor_publish(A, &s_cursor);
-    flush_stats(A, n_seg, n_shadow, RTW_K_BOUNCE);
+    cursor_publish(A, s_cursor, n_seg, n_shadow, RTW_K_BOUNCE);
 }
 
 // sums the S sample slots of every pixel in ascending sample order (fixed order => reproducible bits)
