@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdlib>
+#include <fstream>
 #include <iostream>
 
 #include "SceneMarshal.h"
@@ -94,4 +95,40 @@ void Director::printPPM() {
         }
         std::cout << line;
     }
+}
+
+bool Director::writeBinaryPPM(const std::string& path) const {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    f << "P6\n" << m_Nx << " " << m_Ny << "\n255\n";
+    auto enc = [](float c) {
+        float g = std::sqrt(c);
+        g = g < 0.f ? 0.f : (g > 1.f ? 1.f : g);
+        if (!(g == g)) g = 0.f;
+        return static_cast<unsigned char>(static_cast<int>(255.99f * g));
+    };
+    std::vector<unsigned char> row(static_cast<size_t>(m_Nx) * 3);
+    for (int j = m_Ny - 1; j >= 0; j--) {  // the buffer is bottom-up like the reference's, image files are top-down
+        for (int i = 0; i < m_Nx; i++) {
+            const float* px = &m_hostBuffer[(static_cast<size_t>(m_Nx) * j + i) * 4];
+            row[3 * i] = enc(px[0]); row[3 * i + 1] = enc(px[1]); row[3 * i + 2] = enc(px[2]);
+        }
+        f.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size()));
+    }
+    return static_cast<bool>(f);
+}
+
+bool Director::writePFM(const std::string& path) const {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    f << "PF\n" << m_Nx << " " << m_Ny << "\n-1.0\n";  // negative scale = little-endian; PFM rows run bottom-up
+    std::vector<float> row(static_cast<size_t>(m_Nx) * 3);
+    for (int j = 0; j < m_Ny; j++) {
+        for (int i = 0; i < m_Nx; i++) {
+            const float* px = &m_hostBuffer[(static_cast<size_t>(m_Nx) * j + i) * 4];
+            row[3 * i] = px[0]; row[3 * i + 1] = px[1]; row[3 * i + 2] = px[2];
+        }
+        f.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(float)));
+    }
+    return static_cast<bool>(f);
 }

@@ -70,13 +70,13 @@ def intersect(blob, rays, ray_time=None, gather_time=None):
     return t, prim
 
 
-def cluttered_cornell(w, h, n_extra=40, seed=7):
+def cluttered_cornell(w, h, n_extra=40, seed=7, scene=0):
     """Cornell box (reference scene 0) with n_extra small spheres added: > 24 primitives, so the HIP library walks
     its BVH, and the scene keeps its rect light, so queued shadow probes go through the tree as well. Synthetic
     (not a reference scene): exercises tree + light sampling + transforms together."""
     import numpy as np
     from raytracing_weekend_amd import abi
-    parts = abi.parse_scene(abi.build_scene(0, w, h))
+    parts = abi.parse_scene(abi.build_scene(scene, w, h))  # scene=3: the fog boxes stay in, so the fused path walks the tree
     prims = list(parts["prims"])
     n_mat = len(parts["materials"])
     rs = np.random.RandomState(seed)
