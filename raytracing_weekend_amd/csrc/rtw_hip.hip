@@ -54,7 +54,7 @@ struct rtw_ctx {
         hipEvent_t ev_done = nullptr, ev_free = nullptr;
         PathBuf buf[2] = {};
         uint2* hit[2] = {nullptr, nullptr};
-        void* slab[2] = {nullptr, nullptr};  // one allocation per ping-pong set: six planes + hit records, staggered
+        void* slab[2] = {nullptr, nullptr};  // one allocation per ping-pong set: six planes + hit records
         float4* lbuf = nullptr;
         uint32_t* cnt = nullptr;
         size_t cnt_words = 0;
@@ -110,17 +110,13 @@ int ensure_lane(rtw_ctx* c, rtw_ctx::Lane& L, size_t paths, size_t cnt_words) {
     }
     if (paths > L.paths) {
         free_lane(L);
-        // The planes of one set are read and written at the same slot index by every wave. Equal-sized separate
-        // allocations would put slot s of all planes on the same HBM channel; inside one slab each plane starts
-        // at an optional extra offset (RTW_PLANE_STAGGER bytes apart; measured: no effect on MI355X, default 0).
-        size_t stagger = 0;
-        if (const char* e = getenv("RTW_PLANE_STAGGER")) stagger = (size_t)atoll(e) & ~(size_t)255;
+        // the six state planes and the hit records of one ping-pong set live in one slab, page-aligned
         const size_t plane = (paths * sizeof(float4) + 4095) & ~(size_t)4095;
         for (int b = 0; b < 2; b++) {
-            const size_t total = 7 * plane + 8 * stagger + 4096;
+            const size_t total = 7 * plane + 4096;
             HIP_TRY(c, hipMalloc(&L.slab[b], total));
             char* base = (char*)L.slab[b];
-            auto at = [&](int k) { return base + (size_t)k * plane + (size_t)k * stagger; };
+            auto at = [&](int k) { return base + (size_t)k * plane; };
             L.buf[b].p0 = (float4*)at(0); L.buf[b].p1 = (float4*)at(1); L.buf[b].p2 = (float4*)at(2);
             L.buf[b].p3 = (float4*)at(3); L.buf[b].p4 = (float4*)at(4); L.buf[b].p5 = (uint4*)at(5);
             L.hit[b] = (uint2*)at(6);
@@ -161,13 +157,40 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
     s2 = l > 0 ? l - 1 : 0;
 }
 
-size_t pool_target_paths() {
-    const char* e = getenv("RTW_POOL_PATHS");
-    if (e && *e) {
-        long long v = atoll(e);
-        if (v >= 1024) return (size_t)v;
-    }
-    return (size_t)1 << 28;  // 67 M paths in flight: 9 GiB of ping-pong state + radiance slots (HBM-sized on purpose: long batches amortise the thin tail launches)
+// Tuning knobs, read from the environment once per call site (defaults are what profiles/ was measured with):
+//   RTW_POOL_PATHS  paths in flight over all lanes (default 2^28: 55 GiB of state, sized for 288 GB of HBM)
+//   RTW_LANES       stream lanes that overlap consecutive batches (default 2; 1..4)
+//   RTW_GRID_MULT   persistent workgroups per CU (default 8 with one lane, 4 with two)
+//   RTW_TAIL_START  first bounce handled by the fused multi-bounce tail launches (default 6)
+//   RTW_FUSED=1     every bounce through the fused k_bounce (what scenes with volumes always do)
+//   RTW_BRUTE_MAX   largest primitive count walked with the scalar-cache brute lists (default 24; 0 forces the BVH)
+//   RTW_LDS_KB      dynamic LDS per workgroup for traversal stacks + staged tree nodes (default 16)
+struct Tuning {
+    size_t pool_paths = (size_t)1 << 28;
+    int lanes = 2;
+    int grid_mult = 0;   // 0 = automatic
+    int tail_start = 6;
+    bool fused = false;
+    int brute_max = kBruteMaxPrims;
+    size_t lds_kb = 16;
+};
+Tuning read_tuning() {
+    Tuning t;
+    auto geti = [](const char* name, long long& out) {
+        const char* e = getenv(name);
+        if (!e || !*e) return false;
+        out = atoll(e);
+        return true;
+    };
+    long long v;
+    if (geti("RTW_POOL_PATHS", v) && v >= 1024) t.pool_paths = (size_t)v;
+    if (geti("RTW_LANES", v)) t.lanes = (int)std::max<long long>(1, std::min<long long>(4, v));
+    if (geti("RTW_GRID_MULT", v)) t.grid_mult = (int)std::max<long long>(1, v);
+    if (geti("RTW_TAIL_START", v)) t.tail_start = (int)std::max<long long>(1, v);
+    if (geti("RTW_FUSED", v)) t.fused = v == 1;
+    if (geti("RTW_BRUTE_MAX", v)) t.brute_max = (int)v;
+    if (geti("RTW_LDS_KB", v)) t.lds_kb = (size_t)std::max<long long>(0, v);
+    return t;
 }
 
 enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE };
@@ -331,9 +354,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         }
         shade[i] = s;
     }
-    int brute_max = kBruteMaxPrims;
-    if (const char* e = getenv("RTW_BRUTE_MAX")) brute_max = atoi(e);  // experiments: 0 forces the BVH path
-    const bool use_bvh = (int)h.n_prims > brute_max;
+    const Tuning tune = read_tuning();
+    const bool use_bvh = (int)h.n_prims > tune.brute_max;
     // order[]: volumes (index order), then -- small scenes only -- the moving spheres, which keep the generic test
     for (uint32_t i = 0; i < h.n_prims; i++) if (rtwbvh::is_volume(prims[i].type)) order.push_back((int32_t)i);
     const int n_vol = (int)order.size();
@@ -444,8 +466,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (use_bvh) {
         // Measured on scene 1 (13 levels, 318 nodes): occupancy is worth more than LDS-resident nodes - 16 KB
         // (the stacks plus the top few levels) beats 22 / 30 / 36 KB by 10-25 %; the work-list statics add 9.3 KB.
-        size_t budget_kb = 16;
-        if (const char* e = getenv("RTW_LDS_KB")) budget_kb = (size_t)std::max(0, atoi(e));
+        const size_t budget_kb = tune.lds_kb;
         const size_t stack_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
         const size_t room = budget_kb * 1024 > stack_bytes ? budget_kb * 1024 - stack_bytes : 0;
         sc.n_lds_nodes = (int32_t)std::min<size_t>(bvh.wide.size(), room / sizeof(BvhNode));
@@ -475,10 +496,10 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     if (npix > 0xffffffffull / 2) return fail(c, RTW_ERR_UNSUPPORTED, "tile too large");
 
     // samples per pass: keep about pool_target paths in flight, split over the lanes
-    int want_lanes = 2;
-    if (const char* e = getenv("RTW_LANES")) want_lanes = std::max(1, std::min(4, atoi(e)));
+    const Tuning tune = read_tuning();
+    const int want_lanes = tune.lanes;
     size_t S = P->samples_per_pass > 0 ? (size_t)P->samples_per_pass
-                                       : std::max<size_t>(1, pool_target_paths() / (size_t)want_lanes / npix);
+                                       : std::max<size_t>(1, tune.pool_paths / (size_t)want_lanes / npix);
     S = std::min<size_t>(S, (size_t)P->spp);
     while (S > 1 && npix * S > 0xfffffff0ull) S--;
     const size_t paths_max = npix * S;
@@ -488,8 +509,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     // the first), so a region of (ceil(chunks / G) + 2) * 256 slots cannot overflow.
     const size_t n_batches = ((size_t)P->spp + S - 1) / S;
     const int n_lanes = (int)std::min<size_t>((size_t)want_lanes, std::max<size_t>(n_batches, 1));
-    uint32_t grid_mult = n_lanes > 1 ? 4u : 8u;
-    if (const char* e = getenv("RTW_GRID_MULT")) grid_mult = (uint32_t)std::max(1, atoi(e));
+    const uint32_t grid_mult = tune.grid_mult > 0 ? (uint32_t)tune.grid_mult : (n_lanes > 1 ? 4u : 8u);
     auto grid_for = [&](size_t paths) {
         const size_t chunks = (paths + kBlock - 1) / kBlock;
         return (uint32_t)std::min<size_t>(std::min<size_t>(chunks, (size_t)c->n_cu * grid_mult), (size_t)kMaxRegions);
@@ -508,9 +528,8 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     struct Step { int kind, depth, n_iter; };
     std::vector<Step> sched;
     {
-        const char* e = getenv("RTW_TAIL_START");
-        const int tail_start = (e && *e) ? std::max(1, atoi(e)) : 6;
-        const bool split = c->sc.n_vol == 0 && !(getenv("RTW_FUSED") && getenv("RTW_FUSED")[0] == '1');
+        const int tail_start = tune.tail_start;
+        const bool split = c->sc.n_vol == 0 && !tune.fused;
         int d = 0, grp = 2, rep = 0;
         while (d < P->max_depth) {
             if (d < tail_start) {

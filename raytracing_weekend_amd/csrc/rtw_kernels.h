@@ -188,11 +188,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     if (hr.mat_type != RTW_MAT_DIFFUSE_LIGHT && hr.mat_type != RTW_MAT_NORMAL) g.warm();
     v3 hp, hn;
     hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
-#ifdef RTW_ABLATE_LAMBERT  // timing experiment only (wrong images): every surface shades as lambertian
-    const int mtype = hr.mat_type == RTW_MAT_DIFFUSE_LIGHT ? RTW_MAT_DIFFUSE_LIGHT : RTW_MAT_LAMBERTIAN;
-#else
     const int mtype = hr.mat_type;
-#endif
     const float mparam = hr.param;
     const v3 tex = V(hr.r, hr.g, hr.b);
     int ev;
@@ -398,7 +394,6 @@ RTW_DEV void finish_path(const KArgs& A, uint32_t path_id, v3 L) {
     float lx = (L.x == L.x) ? L.x : 0.f, ly = (L.y == L.y) ? L.y : 0.f, lz = (L.z == L.z) ? L.z : 0.f;
     A.lbuf[path_id] = make_float4(lx, ly, lz, 0.f);
 }
-// wave64 ballot + popcount prefix; one atomic per wave reserves its slice of the region's output
 // Stream compaction without global atomics: output region b belongs to workgroup b, whose four waves share a
 // cursor in LDS (agent-scope atomics are resolved beyond the XCD's L2 on this part, ~0.4 us each and serialised per
 // address). The host sizes a region for the most paths one workgroup of the persistent grid can be handed.

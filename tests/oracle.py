@@ -88,3 +88,97 @@ def cluttered_cornell(w, h, n_extra=40, seed=7, scene=0):
     parts = dict(parts)
     parts["prims"] = prims
     return abi.assemble_scene(parts)
+
+
+def random_scene(seed, w, h, n_prims=30, volumes=False, motion=False, n_lights=1, sky=False):
+    """A synthetic scene for fuzzing GPU-vs-oracle parity: every primitive kind under random rigid transforms, every
+    material kind, 0..n rectangle lights in the light list, optional sky light / volumes / moving spheres. The camera,
+    the image plane and the pdf record come from the Cornell box header (the content sits in its 0..555 cube)."""
+    import ctypes as C
+    import numpy as np
+    from raytracing_weekend_amd import abi
+    rs = np.random.RandomState(seed)
+    parts = dict(abi.parse_scene(abi.build_scene(0, w, h)))
+    hdr = abi.SceneHeader.from_buffer_copy(bytes(parts["header"]))
+    hdr.sky_light = 1 if sky else 0
+
+    def xform(rot_axis, deg, t):
+        a = np.deg2rad(deg)
+        c, s = np.cos(a), np.sin(a)
+        r = np.eye(4)
+        i, j = [(1, 2), (0, 2), (0, 1)][rot_axis]
+        r[i, i], r[i, j], r[j, i], r[j, j] = c, -s, s, c
+        m = np.eye(4)
+        m[:3, 3] = t
+        m = m @ r
+        x = abi.Xform()
+        mi = np.linalg.inv(m)
+        for k in range(12):
+            x.m[k] = float(np.float32(m[k // 4, k % 4]))
+            x.inv[k] = float(np.float32(mi[k // 4, k % 4]))
+        return x
+    ident = abi.Xform()
+    for k in (0, 5, 10):
+        ident.m[k] = ident.inv[k] = 1.0
+    xforms = [ident] + [xform(int(rs.randint(3)), float(rs.uniform(-40, 40)), rs.uniform(-60, 60, 3)) for _ in range(3)]
+
+    textures, materials = [], []
+
+    def tex(rgb):
+        t = abi.Texture(type=abi.TEX_CONSTANT)
+        t.color[0], t.color[1], t.color[2] = (float(v) for v in rgb)
+        textures.append(t)
+        return len(textures) - 1
+    for _ in range(3):
+        materials.append(abi.Material(type=abi.MAT_LAMBERTIAN, texture=tex(rs.uniform(0.1, 0.9, 3)), fuzz_or_eta=0.0, bsdf_eval=0))
+    materials.append(abi.Material(type=abi.MAT_METAL, texture=tex(rs.uniform(0.5, 0.95, 3)), fuzz_or_eta=float(rs.uniform(0, 0.5)), bsdf_eval=2))
+    materials.append(abi.Material(type=abi.MAT_DIELECTRIC, texture=-1, fuzz_or_eta=1.5, bsdf_eval=1))
+    i_light = len(materials)
+    materials.append(abi.Material(type=abi.MAT_DIFFUSE_LIGHT, texture=tex((9.0, 8.0, 7.0)), fuzz_or_eta=0.0, bsdf_eval=-1))
+    materials.append(abi.Material(type=abi.MAT_NORMAL, texture=-1, fuzz_or_eta=0.0, bsdf_eval=-1))
+    i_iso = len(materials)
+    materials.append(abi.Material(type=abi.MAT_ISOTROPIC, texture=tex(rs.uniform(0.3, 0.9, 3)), fuzz_or_eta=0.0, bsdf_eval=-1))
+    surface = [0, 1, 2, 3, 4, 6]
+
+    prims, lights = [], []
+
+    def add(ptype, params, material, xf=0, flip=0):
+        pr = abi.Prim(type=ptype, material=material, xform=xf, flip=flip)
+        for k, v in enumerate(params):
+            pr.p[k] = float(np.float32(v))
+        prims.append(pr)
+    # the light(s): y-rectangles near the ceiling, the first one is the rectangle the pdf record samples
+    rect = [float(hdr.pdf.rect[k]) for k in range(5)]
+    for li in range(n_lights):
+        x0, x1, z0, z1, k = rect if li == 0 else (float(rs.uniform(50, 250)), float(rs.uniform(300, 500)), float(rs.uniform(50, 250)), float(rs.uniform(300, 500)), 540.0 - 10.0 * li)
+        add(abi.PRIM_RECT_Y, (x0, x1, z0, z1, k), i_light, flip=1)
+        lt = abi.Light()
+        lt.position[0], lt.position[1], lt.position[2] = x0, k, z0
+        lt.vec_u[0], lt.vec_u[1], lt.vec_u[2] = x1 - x0, 0.0, 0.0
+        lt.vec_v[0], lt.vec_v[1], lt.vec_v[2] = 0.0, 0.0, z1 - z0
+        lt.normal[0], lt.normal[1], lt.normal[2] = 0.0, -1.0, 0.0
+        lt.area = float(np.float32((x1 - x0) * (z1 - z0)))
+        lt.emission[0], lt.emission[1], lt.emission[2] = 9.0, 8.0, 7.0
+        lights.append(lt)
+    # a floor so that most paths bounce
+    add(abi.PRIM_RECT_Y, (-200, 755, -200, 755, 0.0), 0)
+    while len(prims) < n_prims:
+        kind = rs.randint(0, 10)
+        xf = int(rs.randint(0, len(xforms))) if rs.rand() < 0.5 else 0
+        mat = surface[int(rs.randint(len(surface)))]
+        c = rs.uniform(60, 495, 3)
+        if kind < 4:
+            add(abi.PRIM_SPHERE, (c[0], c[1], c[2], rs.uniform(15, 70)), mat, xf)
+        elif kind < 5 and motion:
+            c1 = c + rs.uniform(-40, 40, 3)
+            add(abi.PRIM_MOVING_SPHERE, (c[0], c[1], c[2], rs.uniform(15, 50), c1[0], c1[1], c1[2], 0.0, 1.0), mat, xf)
+        elif kind < 8:
+            a0, b0 = rs.uniform(20, 400, 2)
+            add(abi.PRIM_RECT_X + int(rs.randint(3)), (a0, a0 + rs.uniform(30, 200), b0, b0 + rs.uniform(30, 200), rs.uniform(20, 535)), mat, xf, int(rs.randint(2)))
+        elif kind < 9 and volumes:
+            lo = rs.uniform(60, 350, 3)
+            add(abi.PRIM_VOLUME_BOX, (lo[0], lo[1], lo[2], lo[0] + rs.uniform(60, 180), lo[1] + rs.uniform(60, 180), lo[2] + rs.uniform(60, 180), rs.uniform(0.002, 0.02)), i_iso, xf)
+        elif volumes:
+            add(abi.PRIM_VOLUME_SPHERE, (c[0], c[1], c[2], rs.uniform(40, 110), rs.uniform(0.002, 0.02)), i_iso, xf)
+    parts.update(header=hdr, prims=prims, xforms=xforms, materials=materials, textures=textures, lights=lights)
+    return abi.assemble_scene(parts)

@@ -102,6 +102,48 @@ def test_tree_scene_with_volumes_matches_oracle(gpu):
         check(img, ref, st, st_ref)
 
 
+FUZZ = [
+    (11, dict(n_prims=10)),                                     # brute lists, transforms, one light
+    (12, dict(n_prims=20, motion=True)),                        # brute lists + moving spheres (generic k_trace)
+    (13, dict(n_prims=24, n_lights=3)),                         # several lights: the light index is drawn
+    (14, dict(n_prims=16, sky=True, n_lights=0)),               # sky only, no light list
+    (15, dict(n_prims=40)),                                     # tree
+    (16, dict(n_prims=80, motion=True, n_lights=2, sky=True)),  # tree + motion + lights + sky
+    (17, dict(n_prims=14, volumes=True)),                       # volumes + light: fused path, brute lists
+    (18, dict(n_prims=70, volumes=True, motion=True, n_lights=2)),  # volumes + tree + motion
+    (19, dict(n_prims=300, n_lights=1)),                        # deeper tree, heavy overlap
+]
+
+
+@pytest.mark.parametrize("seed,kw", FUZZ)
+def test_random_scenes_match_oracle(gpu, seed, kw):
+    """Synthetic scenes (tests/oracle.py random_scene): every primitive kind under random rigid transforms, every
+    material, 0..3 lights, sky, volumes, motion - bit-exact against the oracle for both generators."""
+    w, h = 80, 60
+    blob = oracle.random_scene(seed, w, h, **kw)
+    gpu.upload_scene(blob)
+    for rng in (abi.RTW_RNG_PHILOX, abi.RTW_RNG_TEA_LCG):
+        p = abi.make_params(w, h, 4, 40, rng_kind=rng)
+        img, st = gpu.render(p)
+        ref, st_ref = oracle.render(blob, p, threads=16)
+        check(img, ref, st, st_ref)
+
+
+def test_random_scenes_sweep(gpu):
+    """Forty more fuzzed scenes, one generator each (options derived from the seed), ragged image sizes."""
+    rs = np.random.RandomState(2024)
+    for seed in range(100, 140):
+        kw = dict(n_prims=int(rs.randint(4, 140)), volumes=bool(rs.randint(2)), motion=bool(rs.randint(2)),
+                  n_lights=int(rs.randint(0, 4)), sky=bool(rs.randint(2)))
+        w, h = int(rs.randint(17, 90)), int(rs.randint(17, 70))
+        blob = oracle.random_scene(seed, w, h, **kw)
+        gpu.upload_scene(blob)
+        p = abi.make_params(w, h, int(rs.randint(1, 6)), int(rs.randint(1, 30)), rng_kind=int(seed & 1), seed=int(rs.randint(1, 1 << 30)))
+        img, st = gpu.render(p)
+        ref, st_ref = oracle.render(blob, p, threads=16)
+        assert np.array_equal(img, ref) and st.segments == st_ref.segments and st.shadow_rays == st_ref.shadow_rays, (seed, kw, w, h)
+
+
 def test_edge_cases(gpu):
     blob = abi.build_scene(0, 8, 8)
     gpu.upload_scene(blob)
