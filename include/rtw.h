@@ -118,12 +118,22 @@ typedef struct rtw_material {
     int32_t bsdf_eval;  /* MaterialParams.lightreflectIdx - CALLABLE_ID_LIGHT_SAMPLE_PDF: 0 diffuse, 1 dielectric, 2 metal, -1 none */
 } rtw_material; /* 16 B */
 
+/* textureParam (lib/raydata.cuh:127-138) without its device pointers: tables and texels live in the blob's texture
+ * data section (rtw_scene_header.off_texdata), addressed in 4-byte words from the start of that section.
+ *   RTW_TEX_CONSTANT  color                                  (texture/constantTexture.cu)
+ *   RTW_TEX_CHECKER   odd / even = indices into textures[]   (texture/checkeredTexture.cu; the reference stores the
+ *                     children's callable ids and so never shows a checker - here the children are evaluated)
+ *   RTW_TEX_NOISE     scale; data -> float ranvec[256][3], int32 perm_x[256], perm_y[256], perm_z[256]
+ *                     (texture/noiseTexture.cu, ioTexture.h:118-222)
+ *   RTW_TEX_IMAGE     data -> uint32 width, height, then width*height texels r | g<<8 | b<<16 | a<<24, row 0 at
+ *                     v = 0 (texture/imageTexture.cu; ioTexture.h:225-262 flips the file's rows the same way);
+ *                     sampled bilinearly, clamped, texel centres at (i + 0.5) / width                        */
 typedef struct rtw_texture {
     int32_t type; /* rtw_texture_type */
     float color[3];
     int32_t odd, even;
     float scale;
-    int32_t reserved;
+    uint32_t data; /* word offset into the texture data section (noise, image), else 0 */
 } rtw_texture; /* 32 B */
 
 typedef struct rtw_light {
@@ -164,7 +174,8 @@ typedef struct rtw_scene_header {
     uint32_t n_prims, n_xforms, n_materials, n_textures, n_lights;
     uint32_t off_prims, off_xforms, off_materials, off_textures, off_lights;
     int32_t sky_light; /* SysParamter.skyLight */
-    uint32_t reserved[2];
+    uint32_t off_texdata;   /* byte offset of the texture data section (0 = none)  */
+    uint32_t texdata_bytes; /* its size; rtw_texture.data counts 4-byte words in it */
     rtw_camera camera;
     rtw_pdf pdf;
 } rtw_scene_header;

@@ -228,6 +228,8 @@ typedef struct {
     const rtw_material* mats;
     const rtw_texture* texs;
     const rtw_light* lights;
+    const uint32_t* texdata; /* texture data section, texdata_words 4-byte words */
+    uint32_t texdata_words;
 } scene_t;
 
 static int scene_open(scene_t* s, const void* blob, size_t bytes) {
@@ -252,7 +254,107 @@ static int scene_open(scene_t* s, const void* blob, size_t bytes) {
         if (s->prims[i].xform < 0 || (uint32_t)s->prims[i].xform >= h->n_xforms) return RTW_ERR_BAD_SCENE;
         if (s->prims[i].material < 0 || (uint32_t)s->prims[i].material >= h->n_materials) return RTW_ERR_BAD_SCENE;
     }
+    s->texdata = NULL;
+    s->texdata_words = 0;
+    if (h->off_texdata) {
+        if ((h->off_texdata & 3u) || (size_t)h->off_texdata + (size_t)h->texdata_bytes > bytes) return RTW_ERR_BAD_SCENE;
+        s->texdata = (const uint32_t*)(b + h->off_texdata);
+        s->texdata_words = h->texdata_bytes / 4u;
+    }
+    for (uint32_t i = 0; i < h->n_materials; i++)
+        if (s->mats[i].texture >= (int32_t)h->n_textures) return RTW_ERR_BAD_SCENE;
+    for (uint32_t i = 0; i < h->n_textures; i++) {
+        const rtw_texture* t = &s->texs[i];
+        if (t->type == RTW_TEX_CHECKER) {
+            /* children: any texture but another checker (the reference's callables cannot nest either) */
+            if (t->odd < 0 || t->even < 0 || (uint32_t)t->odd >= h->n_textures || (uint32_t)t->even >= h->n_textures) return RTW_ERR_BAD_SCENE;
+            if (s->texs[t->odd].type == RTW_TEX_CHECKER || s->texs[t->even].type == RTW_TEX_CHECKER) return RTW_ERR_BAD_SCENE;
+        } else if (t->type == RTW_TEX_NOISE) {
+            if ((size_t)t->data + 1536u > s->texdata_words) return RTW_ERR_BAD_SCENE;
+        } else if (t->type == RTW_TEX_IMAGE) {
+            if ((size_t)t->data + 2u > s->texdata_words) return RTW_ERR_BAD_SCENE;
+            uint32_t iw = s->texdata[t->data], ih = s->texdata[t->data + 1];
+            if (iw == 0 || ih == 0 || iw > 32768u || ih > 32768u || (size_t)t->data + 2u + (size_t)iw * ih > s->texdata_words) return RTW_ERR_BAD_SCENE;
+        } else if (t->type != RTW_TEX_CONSTANT && t->type != RTW_TEX_NULL) {
+            return RTW_ERR_BAD_SCENE;
+        }
+    }
     return RTW_OK;
+}
+
+/* ------------------------------------------------------------------ sin / atan2 / asin (texture callables)
+ * The reference calls sinf (texture/noiseTexture.cu:77, checkeredTexture.cu:9), atan2f and asinf
+ * (geometry/sphere.cu:24-30) from libdevice under fast-math. Restated with the published Cephes single-precision
+ * algorithms (sinf.c, atanf.c, asinf.c), every fused step written as fmaf so that the HIP build repeats it bit for
+ * bit. The numbers differ from libdevice's in the last ulps: texture parity against OptiX is unpinned. */
+float rtwo_sinf(float xx) {
+    float x = fabsf(xx);
+    int sign = xx < 0.0f ? -1 : 1;
+    /* octant: j = (int)(x * 4/pi), made even */
+    uint32_t j = (uint32_t)(x * 1.27323954473516f);
+    float y = (float)j;
+    if (j & 1u) { j += 1u; y += 1.0f; }
+    j &= 7u;
+    if (j > 3u) { sign = -sign; j -= 4u; }
+    /* extended-precision modular arithmetic: x - y * pi/4 in three steps */
+    x = fmaf(-y, 0.78515625f, x);
+    x = fmaf(-y, 2.4187564849853515625e-4f, x);
+    x = fmaf(-y, 3.77489497744594108e-8f, x);
+    float z = x * x, r;
+    if (j == 1u || j == 2u) {
+        float p = fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+        p = fmaf(p, z, 4.166664568298827e-2f);
+        r = fmaf(p * z, z, fmaf(-0.5f, z, 1.0f));
+    } else {
+        float p = fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f);
+        p = fmaf(p, z, -1.6666654611e-1f);
+        r = fmaf(p * z, x, x);
+    }
+    return sign < 0 ? -r : r;
+}
+
+static float atan_pos(float x) { /* x >= 0 */
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    float z = x * x;
+    float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    return y + fmaf(p * z, x, x);
+}
+
+float rtwo_atan2f(float y, float x) {
+    const float pi = 3.14159265358979323846f, pio2 = 1.5707963267948966f;
+    if (x == 0.0f) return y > 0.0f ? pio2 : (y < 0.0f ? -pio2 : 0.0f);
+    if (y == 0.0f) return x < 0.0f ? pi : 0.0f;
+    float q = y / x;
+    float a = atan_pos(fabsf(q));
+    if (q < 0.0f) a = -a;
+    float w = x < 0.0f ? (y < 0.0f ? -pi : pi) : 0.0f;
+    return w + a;
+}
+
+float rtwo_asinf(float xx) { /* arguments beyond +-1 (rounding of a unit normal) are clamped */
+    float a = fabsf(xx);
+    if (a > 1.0f) a = 1.0f;
+    float r;
+    if (a < 1.0e-4f) {
+        r = a;
+    } else {
+        float z, x;
+        int flag = a > 0.5f;
+        if (flag) { z = 0.5f * (1.0f - a); x = sqrtf(z); }
+        else { x = a; z = x * x; }
+        float p = fmaf(4.2163199048e-2f, z, 2.4181311049e-2f);
+        p = fmaf(p, z, 4.5470025998e-2f);
+        p = fmaf(p, z, 7.4953002686e-2f);
+        p = fmaf(p, z, 1.6666752422e-1f);
+        r = fmaf(p * z, x, x);
+        if (flag) r = 1.5707963267948966f - (r + r);
+    }
+    return xx < 0.0f ? -r : r;
 }
 
 /* ------------------------------------------------------------------ intersection */
@@ -424,17 +526,27 @@ static void traverse(const scene_t* sc, v3 o, v3 d, float tmin, float tmax, floa
  * optixReportIntersection registers 0..7). u,v are not produced: only constant/null textures are in scope.
  * The world point is the world ray evaluated at t — the same real point as the reference's
  * optixTransformPointFromObjectToWorldSpace(o_obj + t*d_obj), without the round trip through object space. */
-static void hit_attributes(const scene_t* sc, const hit_t* h, v3 o, v3 d, v3* point, v3* normal) {
+/* geometry/sphere.cu:24-30 get_sphere_uv, applied to the (unnormalised) shading normal */
+static void sphere_uv(v3 n, float* u, float* v) {
+    float phi = rtwo_atan2f(n.z, n.x);
+    float theta = rtwo_asinf(n.y);
+    *u = 1.0f - (phi + 3.14159265358979323846f) / 6.28318530717958647692f;
+    *v = (theta + 1.57079632679489661923f) / 3.14159265358979323846f;
+}
+
+static void hit_attributes(const scene_t* sc, const hit_t* h, v3 o, v3 d, v3* point, v3* normal, float* tu, float* tv) {
     const rtw_prim* pr = &sc->prims[h->prim];
     const rtw_xform* xf = &sc->xforms[pr->xform];
     v3 pw = vfma(d, h->t, o);
     *point = pw;
+    *tu = 0.0f; *tv = 0.0f;
     switch (pr->type) {
     case RTW_PRIM_SPHERE: {
         /* sphere.cu:63-67: normal from the WORLD point and the OBJECT-space centre (quirk Q13) */
         v3 n = vscale(vsub(pw, ld3(&pr->p[0])), 1.0f / pr->p[3]);
         if (pr->xform != 0) n = xf_normal(xf->inv, n);
         *normal = n;
+        sphere_uv(n, tu, tv);
         break;
     }
     case RTW_PRIM_MOVING_SPHERE: {
@@ -442,6 +554,7 @@ static void hit_attributes(const scene_t* sc, const hit_t* h, v3 o, v3 d, v3* po
         v3 n = vscale(vsub(pw, h->xcenter), 1.0f / pr->p[3]);
         if (pr->xform != 0) n = xf_normal(xf->inv, n);
         *normal = n;
+        sphere_uv(n, tu, tv);
         break;
     }
     case RTW_PRIM_RECT_X:
@@ -450,9 +563,17 @@ static void hit_attributes(const scene_t* sc, const hit_t* h, v3 o, v3 d, v3* po
         v3 n = (pr->type == RTW_PRIM_RECT_X) ? V(1.f, 0.f, 0.f) : (pr->type == RTW_PRIM_RECT_Y) ? V(0.f, 1.f, 0.f) : V(0.f, 0.f, 1.f);
         if (pr->flip) n = vneg(n);
         *normal = (pr->xform != 0) ? normalize3(xf_normal(xf->inv, n)) : n; /* normalize of an exact unit axis is the identity */
+        /* aarectx.cu:33-34 (y,z), aarecty.cu (x,z), aarectz.cu (x,y): the in-plane coordinates of the object-space hit */
+        float oa, da, ob, db;
+        if (pr->type == RTW_PRIM_RECT_X) { oa = h->o_obj.y; da = h->d_obj.y; ob = h->o_obj.z; db = h->d_obj.z; }
+        else if (pr->type == RTW_PRIM_RECT_Y) { oa = h->o_obj.x; da = h->d_obj.x; ob = h->o_obj.z; db = h->d_obj.z; }
+        else { oa = h->o_obj.x; da = h->d_obj.x; ob = h->o_obj.y; db = h->d_obj.y; }
+        float a = fmaf(h->t, da, oa), b = fmaf(h->t, db, ob);
+        *tu = (a - pr->p[0]) / (pr->p[1] - pr->p[0]);
+        *tv = (b - pr->p[2]) / (pr->p[3] - pr->p[2]);
         break;
     }
-    default: { /* volumes: volumeBox.cu:86-93, volumeSphere.cu:97-105 */
+    default: { /* volumes: volumeBox.cu:86-93, volumeSphere.cu:97-105 (u = v = 0) */
         v3 n = V(1.f, 0.f, 0.f);
         *normal = (pr->xform != 0) ? normalize3(xf_normal(xf->inv, n)) : n;
         break;
@@ -460,12 +581,95 @@ static void hit_attributes(const scene_t* sc, const hit_t* h, v3 o, v3 d, v3* po
     }
 }
 
-/* texture callables in scope: texture/constantTexture.cu:5-10, nullTexture.cu:7-12 */
-static v3 texture_value(const scene_t* sc, const rtw_material* m) {
-    if (m->texture < 0) return V(0.f, 0.f, 0.f);
-    const rtw_texture* t = &sc->texs[m->texture];
-    if (t->type == RTW_TEX_CONSTANT) return ld3(t->color);
-    return V(0.f, 0.f, 0.f);
+/* ---- texture callables: texture/constantTexture.cu:5-10, nullTexture.cu:7-12, checkeredTexture.cu:8-19,
+ * noiseTexture.cu:20-78, imageTexture.cu:11-17 ---- */
+static float perlin_noise(const uint32_t* tab, v3 p) {
+    const float* ranvec = (const float*)tab;
+    const int32_t* px = (const int32_t*)(tab + 768);
+    const int32_t* py = px + 256;
+    const int32_t* pz = py + 256;
+    float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    int i = (int)fx, j = (int)fy, k = (int)fz;
+    /* perlin_interp, noiseTexture.cu:20-36 */
+    float uu = (u * u) * (3.0f - 2.0f * u);
+    float vv = (v * v) * (3.0f - 2.0f * v);
+    float ww = (w * w) * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+    for (int di = 0; di < 2; di++)
+        for (int dj = 0; dj < 2; dj++)
+            for (int dk = 0; dk < 2; dk++) {
+                int idx = (px[(i + di) & 255] ^ py[(j + dj) & 255] ^ pz[(k + dk) & 255]) & 255;
+                v3 c = V(ranvec[3 * idx], ranvec[3 * idx + 1], ranvec[3 * idx + 2]);
+                v3 wv = V(u - (float)di, v - (float)dj, w - (float)dk);
+                float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
+                accum = accum + ((wi * wj) * wk) * dot3(c, wv);
+            }
+    return accum;
+}
+
+static float perlin_turb(const uint32_t* tab, v3 p) { /* noiseTexture.cu:54-67, 7 octaves */
+    float accum = 0.0f, weight = 1.0f;
+    v3 tp = p;
+    for (int i = 0; i < 7; i++) {
+        accum = accum + weight * perlin_noise(tab, tp);
+        weight = weight * 0.5f;
+        tp = vscale(tp, 2.0f);
+    }
+    return fabsf(accum);
+}
+
+static v3 image_fetch(const uint32_t* img, float u, float v) {
+    /* tex2D, normalised coordinates, clamp addressing, linear filter, 8-bit texels read as x/255
+     * (ioTexture.h:264-283). The hardware filter rounds its weights to 8 fractional bits; this one keeps fp32. */
+    const uint32_t W = img[0], H = img[1];
+    const uint32_t* tex = img + 2;
+    if (!(u == u)) u = 0.0f;
+    if (!(v == v)) v = 0.0f;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    x = fminf(fmaxf(x, -1.0f), (float)W);
+    y = fminf(fmaxf(y, -1.0f), (float)H);
+    float x0 = floorf(x), y0 = floorf(y);
+    float a = x - x0, b = y - y0;
+    int ix = (int)x0, iy = (int)y0;
+    int ix0 = ix < 0 ? 0 : (ix > (int)W - 1 ? (int)W - 1 : ix), ix1 = ix + 1 < 0 ? 0 : (ix + 1 > (int)W - 1 ? (int)W - 1 : ix + 1);
+    int iy0 = iy < 0 ? 0 : (iy > (int)H - 1 ? (int)H - 1 : iy), iy1 = iy + 1 < 0 ? 0 : (iy + 1 > (int)H - 1 ? (int)H - 1 : iy + 1);
+    uint32_t t00 = tex[(size_t)iy0 * W + ix0], t10 = tex[(size_t)iy0 * W + ix1], t01 = tex[(size_t)iy1 * W + ix0], t11 = tex[(size_t)iy1 * W + ix1];
+    float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float rgb[3];
+    for (int ch = 0; ch < 3; ch++) {
+        float c00 = (float)((t00 >> (8 * ch)) & 255u) / 255.0f, c10 = (float)((t10 >> (8 * ch)) & 255u) / 255.0f;
+        float c01 = (float)((t01 >> (8 * ch)) & 255u) / 255.0f, c11 = (float)((t11 >> (8 * ch)) & 255u) / 255.0f;
+        rgb[ch] = ((w00 * c00 + w10 * c10) + w01 * c01) + w11 * c11;
+    }
+    return V(rgb[0], rgb[1], rgb[2]);
+}
+
+static v3 texture_eval(const scene_t* sc, int ti, float u, float v, v3 p) {
+    if (ti < 0) return V(0.f, 0.f, 0.f);
+    const rtw_texture* t = &sc->texs[ti];
+    if (t->type == RTW_TEX_CHECKER) {
+        /* checkeredTexture.cu:9: note "10.f - p.y" (kept) */
+        float sines = (rtwo_sinf(10.0f * p.x) * rtwo_sinf(10.0f - p.y)) * rtwo_sinf(10.0f * p.z);
+        t = &sc->texs[sines < 0.0f ? t->odd : t->even]; /* children are never checkers (scene_open) */
+    }
+    switch (t->type) {
+    case RTW_TEX_CONSTANT: return ld3(t->color);
+    case RTW_TEX_NOISE: {
+        /* noiseTexture.cu:77 */
+        const uint32_t* tab = sc->texdata + t->data;
+        float tb = perlin_turb(tab, vscale(p, t->scale));
+        float s = rtwo_sinf(t->scale * p.z + 5.0f * tb);
+        float g = 0.5f * (1.0f + s);
+        return V(g, g, g);
+    }
+    case RTW_TEX_IMAGE: return image_fetch(sc->texdata + t->data, u, v);
+    default: return V(0.f, 0.f, 0.f);
+    }
+}
+
+static v3 texture_value(const scene_t* sc, const rtw_material* m, float u, float v, v3 p) {
+    return texture_eval(sc, m->texture, u, v, p);
 }
 
 /* lib/sampling.cuh:25-34 */
@@ -564,7 +768,8 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
              * lanes of a GPU wave refill their generator at the same call sites (unused words are skipped) */
             if (g.kind == RTW_RNG_PHILOX) { g.draw[1] = (g.draw[1] + 3u) & ~3u; g.seg_base = g.draw[1]; }
             v3 hp, hn;
-            hit_attributes(sc, &h, origin, dir, &hp, &hn);
+            float tu, tv;
+            hit_attributes(sc, &h, origin, dir, &hp, &hn, &tu, &tv);
             const rtw_material* m = &sc->mats[sc->prims[h.prim].material];
             int specular = 0;
             switch (m->type) {
@@ -591,12 +796,12 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
                 float cosine = dot3(hn, sdir);
                 ev = EV_HIT;
                 if (cosine <= 0.0f || pdf <= 0.0f) { ev = EV_CANCEL; break; }
-                att = texture_value(sc, m);
+                att = texture_value(sc, m, tu, tv, hp);
                 break;
             }
             case RTW_MAT_DIFFUSE_LIGHT: {
                 /* material/diffuseLight.cu:48-69 */
-                if (dot3(hn, dir) < 0.0f) radiance = texture_value(sc, m);
+                if (dot3(hn, dir) < 0.0f) radiance = texture_value(sc, m, tu, tv, hp);
                 ev = EV_CANCEL;
                 break;
             }
@@ -607,7 +812,7 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
                 v3 ball = random_in_unit_sphere(&g);
                 v3 sdir = normalize3(vfma(ball, m->fuzz_or_eta, refl));
                 so = hp; sd = sdir;
-                att = texture_value(sc, m);
+                att = texture_value(sc, m, tu, tv, hp);
                 ev = (dot3(sdir, hn) <= 0.0f) ? EV_CANCEL : EV_HIT;
                 break;
             }
@@ -651,7 +856,7 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
                 specular = 1;
                 sd = random_in_unit_sphere(&g);
                 so = hp;
-                att = texture_value(sc, m);
+                att = texture_value(sc, m, tu, tv, hp);
                 ev = EV_HIT;
                 break;
             }

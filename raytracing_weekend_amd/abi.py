@@ -42,7 +42,7 @@ class Material(C.Structure):
 
 class Texture(C.Structure):
     _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("odd", C.c_int32), ("even", C.c_int32),
-                ("scale", C.c_float), ("reserved", C.c_int32)]
+                ("scale", C.c_float), ("data", C.c_uint32)]
 
 
 class Light(C.Structure):
@@ -67,7 +67,7 @@ class SceneHeader(C.Structure):
                 ("n_textures", C.c_uint32), ("n_lights", C.c_uint32),
                 ("off_prims", C.c_uint32), ("off_xforms", C.c_uint32), ("off_materials", C.c_uint32),
                 ("off_textures", C.c_uint32), ("off_lights", C.c_uint32),
-                ("sky_light", C.c_int32), ("reserved", C.c_uint32 * 2),
+                ("sky_light", C.c_int32), ("off_texdata", C.c_uint32), ("texdata_bytes", C.c_uint32),
                 ("camera", Camera), ("pdf", Pdf)]
 
 
@@ -164,12 +164,14 @@ def parse_scene(blob):
         "materials": arr(Material, h.off_materials, h.n_materials),
         "textures": arr(Texture, h.off_textures, h.n_textures),
         "lights": arr(Light, h.off_lights, h.n_lights),
+        "texdata": bytes(blob[h.off_texdata:h.off_texdata + h.texdata_bytes]) if h.off_texdata else b"",
     }
 
 
 def assemble_scene(parts):
-    """Inverse of parse_scene: serialise {"header", "prims", "xforms", "materials", "textures", "lights"} (ctypes
-    arrays or lists of the structs) into a blob; counts, offsets and total_bytes are recomputed."""
+    """Inverse of parse_scene: serialise {"header", "prims", "xforms", "materials", "textures", "lights"[, "texdata"]}
+    (ctypes arrays or lists of the structs, texdata = bytes of the texture data section) into a blob; counts, offsets
+    and total_bytes are recomputed."""
     src = parts["header"]
     h = SceneHeader.from_buffer_copy(bytes(src))
     tables = [list(parts[k]) for k in ("prims", "xforms", "materials", "textures", "lights")]
@@ -179,8 +181,11 @@ def assemble_scene(parts):
     for t, sz in zip(tables, sizes):
         offs.append((offs[-1] + len(t) * sz + 15) // 16 * 16)
     h.off_prims, h.off_xforms, h.off_materials, h.off_textures, h.off_lights = offs[:5]
-    h.total_bytes = offs[5]
-    buf = bytearray(offs[5])
+    texdata = bytes(parts.get("texdata", b""))
+    h.off_texdata, h.texdata_bytes = (offs[5], len(texdata)) if texdata else (0, 0)
+    h.total_bytes = (offs[5] + len(texdata) + 15) // 16 * 16
+    buf = bytearray(h.total_bytes)
+    buf[offs[5]:offs[5] + len(texdata)] = texdata
     buf[0:C.sizeof(SceneHeader)] = bytes(h)
     for t, sz, off in zip(tables, sizes, offs):
         for i, obj in enumerate(t):

@@ -76,6 +76,75 @@ RTW_DEV void sincos2pi(float r, float& s_out, float& c_out) {
     c_out = co;
 }
 
+// sin / atan2 / asin of the texture callables (texture/noiseTexture.cu:77, checkeredTexture.cu:9, geometry/sphere.cu:24-30):
+// Cephes single-precision algorithms (sinf.c, atanf.c, asinf.c) with every fused step written out; the CPU checker in
+// the test tree repeats them operation for operation.
+RTW_DEV float sin_spec(float xx) {
+    float x = __builtin_fabsf(xx);
+    bool neg = xx < 0.0f;
+    uint32_t j = (uint32_t)(x * 1.27323954473516f);
+    float y = (float)j;
+    if (j & 1u) { j += 1u; y += 1.0f; }
+    j &= 7u;
+    if (j > 3u) { neg = !neg; j -= 4u; }
+    x = fma_(-y, 0.78515625f, x);
+    x = fma_(-y, 2.4187564849853515625e-4f, x);
+    x = fma_(-y, 3.77489497744594108e-8f, x);
+    const float z = x * x;
+    float r;
+    if (j == 1u || j == 2u) {
+        float p = fma_(2.443315711809948e-5f, z, -1.388731625493765e-3f);
+        p = fma_(p, z, 4.166664568298827e-2f);
+        r = fma_(p * z, z, fma_(-0.5f, z, 1.0f));
+    } else {
+        float p = fma_(-1.9515295891e-4f, z, 8.3321608736e-3f);
+        p = fma_(p, z, -1.6666654611e-1f);
+        r = fma_(p * z, x, x);
+    }
+    return neg ? -r : r;
+}
+RTW_DEV float atan_pos(float x) {
+    float y;
+    if (x > 2.414213562373095f) { y = 1.5707963267948966f; x = -(1.0f / x); }
+    else if (x > 0.4142135623730950f) { y = 0.7853981633974483f; x = (x - 1.0f) / (x + 1.0f); }
+    else y = 0.0f;
+    const float z = x * x;
+    float p = fma_(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fma_(p, z, 1.99777106478e-1f);
+    p = fma_(p, z, -3.33329491539e-1f);
+    return y + fma_(p * z, x, x);
+}
+RTW_DEV float atan2_spec(float y, float x) {
+    const float pi = 3.14159265358979323846f, pio2 = 1.5707963267948966f;
+    if (x == 0.0f) return y > 0.0f ? pio2 : (y < 0.0f ? -pio2 : 0.0f);
+    if (y == 0.0f) return x < 0.0f ? pi : 0.0f;
+    const float q = y / x;
+    float a = atan_pos(__builtin_fabsf(q));
+    if (q < 0.0f) a = -a;
+    const float w = x < 0.0f ? (y < 0.0f ? -pi : pi) : 0.0f;
+    return w + a;
+}
+RTW_DEV float asin_spec(float xx) {
+    float a = __builtin_fabsf(xx);
+    if (a > 1.0f) a = 1.0f;
+    float r;
+    if (a < 1.0e-4f) {
+        r = a;
+    } else {
+        float z, x;
+        const bool flag = a > 0.5f;
+        if (flag) { z = 0.5f * (1.0f - a); x = __builtin_sqrtf(z); }
+        else { x = a; z = x * x; }
+        float p = fma_(4.2163199048e-2f, z, 2.4181311049e-2f);
+        p = fma_(p, z, 4.5470025998e-2f);
+        p = fma_(p, z, 7.4953002686e-2f);
+        p = fma_(p, z, 1.6666752422e-1f);
+        r = fma_(p * z, x, x);
+        if (flag) r = 1.5707963267948966f - (r + r);
+    }
+    return xx < 0.0f ? -r : r;
+}
+
 // natural log (Cephes logf) — stands in for logf of geometry/volumeBox.cu:79, volumeSphere.cu:93
 RTW_DEV float log_spec(float x) {
     if (x == 0.0f) return -__builtin_inff();
@@ -231,14 +300,14 @@ struct HitRec {
     int32_t mat_type;   // rtw_material_type
     int32_t bsdf_eval;
     float param;        // fuzz or eta
-    int32_t kind;       // HK_*
+    int32_t kind;       // HK_* | (index of a non-constant texture + 1) << 8
     float r, g, b;      // texture colour
     float inv_r;        // spheres: 1/radius (IEEE division, done once on the host)
     float nx, ny, nz;   // HK_CONST_NORMAL: world shading normal (rectangles, volumes); spheres: centre
     int32_t xform;
     // HK_CONST_NORMAL: the orthonormal basis onb::buildFromW(normal) of lib/onb.cuh:20-32, computed once on the
     // host with the same fp32 operations (u = cross(w,v), v = normalize(cross(w,a)), w = normalize(n))
-    float ux, uy, uz, pad0;
+    float ux, uy, uz; int32_t tex_dyn;  // (filled by load_hitrec from kind's high bits; -1 = constant colour in r, g, b)
     float vx, vy, vz, pad1;
     float wx, wy, wz, pad2;
 };
@@ -268,9 +337,11 @@ struct DScene {
     const int32_t* __restrict__ order;       // candidate order: volumes (index order) then the rest (index order)
     const BruteGroup* __restrict__ groups;   // small scenes: primitives regrouped by instance transform and kind
     const BruteRec* __restrict__ recs;
+    const rtw_texture* __restrict__ texs;    // only read for hit records with a non-constant texture
+    const uint32_t* __restrict__ texdata;    // noise tables, image texels (rtw.h rtw_texture)
     int32_t n_prims, n_vol, n_tree, n_lights, sky_light, use_bvh, has_motion, n_groups;
     int32_t n_generic;                       // order[n_vol .. n_vol+n_generic): moving spheres, tested through the generic path
-    int32_t n_lds_nodes, stack_depth, pad2;  // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks
+    int32_t n_lds_nodes, stack_depth, has_tex;  // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks
     float bmin[3], bmax[3];                  // generous world bounds of everything (k_first's wave-uniform miss test)
     rtw_camera cam;
     rtw_pdf pdf;
@@ -725,11 +796,11 @@ RTW_DEV HitRec load_hitrec(const DScene& sc, int prim) {
     const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.hitrec + prim);
     const u32x4 a = q[0], b = q[1], c = q[2];
     HitRec h;
-    h.mat_type = (int)a.x; h.bsdf_eval = (int)a.y; h.param = __uint_as_float(a.z); h.kind = (int)a.w;
+    h.mat_type = (int)a.x; h.bsdf_eval = (int)a.y; h.param = __uint_as_float(a.z); h.kind = (int)(a.w & 255u); h.tex_dyn = (int)(a.w >> 8) - 1;
     h.r = __uint_as_float(b.x); h.g = __uint_as_float(b.y); h.b = __uint_as_float(b.z); h.inv_r = __uint_as_float(b.w);
     h.nx = __uint_as_float(c.x); h.ny = __uint_as_float(c.y); h.nz = __uint_as_float(c.z); h.xform = (int)c.w;
     h.ux = h.uy = h.uz = h.vx = h.vy = h.vz = h.wx = h.wy = h.wz = 0.f;
-    h.pad0 = h.pad1 = h.pad2 = 0.f;
+    h.pad1 = h.pad2 = 0.f;
     if (h.kind == HK_CONST_NORMAL && h.mat_type == RTW_MAT_LAMBERTIAN) {
         const u32x4 d = q[3], e = q[4], f = q[5];
         h.ux = __uint_as_float(d.x); h.uy = __uint_as_float(d.y); h.uz = __uint_as_float(d.z);
@@ -757,6 +828,112 @@ RTW_DEV void hit_attributes(const DScene& sc, const HitRec& h, int prim, v3 o, v
         if (pr.xform != 0) { M34 xi = load_xf_inv(sc, pr.xform); n = xf_normal(xi.m, n); }
         normal = n;
     }
+}
+
+// ---- non-constant textures (cold path: only kernels instantiated with TEX = true contain it) ----
+// geometry/sphere.cu:24-30 on the (unnormalised) shading normal
+RTW_DEV void sphere_uv(v3 n, float& u, float& v) {
+    const float phi = atan2_spec(n.z, n.x);
+    const float theta = asin_spec(n.y);
+    u = 1.0f - (phi + 3.14159265358979323846f) / 6.28318530717958647692f;
+    v = (theta + 1.57079632679489661923f) / 3.14159265358979323846f;
+}
+// u, v of the committed hit: spheres from the shading normal, rectangles from the object-space hit point
+// (aarectx.cu:33-34 and siblings), volumes 0
+RTW_DEV void hit_uv(const DScene& sc, const HitRec& h, int prim, v3 o, v3 d, float t, float ray_time, v3 normal, float& u, float& v) {
+    u = 0.0f; v = 0.0f;
+    if (h.kind != HK_CONST_NORMAL) { sphere_uv(normal, u, v); return; }
+    const rtw_prim pr = load_prim(sc, prim);
+    if (pr.type < RTW_PRIM_RECT_X || pr.type > RTW_PRIM_RECT_Z) return;
+    v3 po, pd, mt;
+    object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+    float oa, da, ob, db;
+    if (pr.type == RTW_PRIM_RECT_X) { oa = po.y; da = pd.y; ob = po.z; db = pd.z; }
+    else if (pr.type == RTW_PRIM_RECT_Y) { oa = po.x; da = pd.x; ob = po.z; db = pd.z; }
+    else { oa = po.x; da = pd.x; ob = po.y; db = pd.y; }
+    const float a = fma_(t, da, oa), b = fma_(t, db, ob);
+    u = (a - pr.p[0]) / (pr.p[1] - pr.p[0]);
+    v = (b - pr.p[2]) / (pr.p[3] - pr.p[2]);
+}
+RTW_DEV float perlin_noise(const uint32_t* __restrict__ tab, v3 p) {  // noiseTexture.cu:20-52
+    const float* ranvec = (const float*)tab;
+    const int32_t* px = (const int32_t*)(tab + 768);
+    const int32_t* py = px + 256;
+    const int32_t* pz = py + 256;
+    const float fx = __builtin_floorf(p.x), fy = __builtin_floorf(p.y), fz = __builtin_floorf(p.z);
+    const float u = p.x - fx, v = p.y - fy, w = p.z - fz;
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const float uu = (u * u) * (3.0f - 2.0f * u);
+    const float vv = (v * v) * (3.0f - 2.0f * v);
+    const float ww = (w * w) * (3.0f - 2.0f * w);
+    float accum = 0.0f;
+#pragma unroll 1
+    for (int c8 = 0; c8 < 8; c8++) {
+        const int di = c8 >> 2, dj = (c8 >> 1) & 1, dk = c8 & 1;
+        const int idx = (px[(i + di) & 255] ^ py[(j + dj) & 255] ^ pz[(k + dk) & 255]) & 255;
+        const v3 c = V(ranvec[3 * idx], ranvec[3 * idx + 1], ranvec[3 * idx + 2]);
+        const v3 wv = V(u - (float)di, v - (float)dj, w - (float)dk);
+        const float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
+        accum = accum + ((wi * wj) * wk) * dot3(c, wv);
+    }
+    return accum;
+}
+RTW_DEV float perlin_turb(const uint32_t* __restrict__ tab, v3 p) {  // noiseTexture.cu:54-67
+    float accum = 0.0f, weight = 1.0f;
+    v3 tp = p;
+#pragma unroll 1
+    for (int i = 0; i < 7; i++) {
+        accum = accum + weight * perlin_noise(tab, tp);
+        weight = weight * 0.5f;
+        tp = vscale(tp, 2.0f);
+    }
+    return __builtin_fabsf(accum);
+}
+RTW_DEV v3 image_fetch(const uint32_t* __restrict__ img, float u, float v) {  // imageTexture.cu:11-17: clamp, bilinear, fp32 weights
+    const uint32_t W = img[0], H = img[1];
+    const uint32_t* tex = img + 2;
+    if (!(u == u)) u = 0.0f;
+    if (!(v == v)) v = 0.0f;
+    float x = u * (float)W - 0.5f, y = v * (float)H - 0.5f;
+    x = __builtin_fminf(__builtin_fmaxf(x, -1.0f), (float)W);
+    y = __builtin_fminf(__builtin_fmaxf(y, -1.0f), (float)H);
+    const float x0 = __builtin_floorf(x), y0 = __builtin_floorf(y);
+    const float a = x - x0, b = y - y0;
+    const int ix = (int)x0, iy = (int)y0, w1 = (int)W - 1, h1 = (int)H - 1;
+    const int ix0 = ix < 0 ? 0 : (ix > w1 ? w1 : ix), ix1 = ix + 1 < 0 ? 0 : (ix + 1 > w1 ? w1 : ix + 1);
+    const int iy0 = iy < 0 ? 0 : (iy > h1 ? h1 : iy), iy1 = iy + 1 < 0 ? 0 : (iy + 1 > h1 ? h1 : iy + 1);
+    const uint32_t t00 = tex[(size_t)iy0 * W + ix0], t10 = tex[(size_t)iy0 * W + ix1], t01 = tex[(size_t)iy1 * W + ix0], t11 = tex[(size_t)iy1 * W + ix1];
+    const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+    float rgb[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+        const float c00 = (float)((t00 >> (8 * ch)) & 255u) / 255.0f, c10 = (float)((t10 >> (8 * ch)) & 255u) / 255.0f;
+        const float c01 = (float)((t01 >> (8 * ch)) & 255u) / 255.0f, c11 = (float)((t11 >> (8 * ch)) & 255u) / 255.0f;
+        rgb[ch] = ((w00 * c00 + w10 * c10) + w01 * c01) + w11 * c11;
+    }
+    return V(rgb[0], rgb[1], rgb[2]);
+}
+// texture/checkeredTexture.cu:8-19, noiseTexture.cu:69-78, imageTexture.cu, constantTexture.cu, nullTexture.cu
+RTW_DEV v3 texture_eval(const DScene& sc, const HitRec& h, int prim, v3 o, v3 d, float t, float ray_time, v3 p, v3 normal) {
+    rtw_texture tx = sc.texs[h.tex_dyn];
+    if (tx.type == RTW_TEX_CHECKER) {
+        const float sines = (sin_spec(10.0f * p.x) * sin_spec(10.0f - p.y)) * sin_spec(10.0f * p.z);
+        tx = sc.texs[sines < 0.0f ? tx.odd : tx.even];
+    }
+    if (tx.type == RTW_TEX_CONSTANT) return V(tx.color[0], tx.color[1], tx.color[2]);
+    if (tx.type == RTW_TEX_NOISE) {
+        const uint32_t* tab = sc.texdata + tx.data;
+        const float tb = perlin_turb(tab, vscale(p, tx.scale));
+        const float sn = sin_spec(tx.scale * p.z + 5.0f * tb);
+        const float g = 0.5f * (1.0f + sn);
+        return V(g, g, g);
+    }
+    if (tx.type == RTW_TEX_IMAGE) {
+        float u, v;
+        hit_uv(sc, h, prim, o, d, t, ray_time, normal, u, v);
+        return image_fetch(sc.texdata + tx.data, u, v);
+    }
+    return V(0.f, 0.f, 0.f);
 }
 
 // lib/sampling.cuh:25-34

@@ -196,24 +196,25 @@ Tuning read_tuning() {
 enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE };
 void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s) {
     const bool lcg = rng_kind == RTW_RNG_TEA_LCG;
+    // kernels that shade exist in four instantiations: RNG kind x "some material has a non-constant texture"
+    const bool tex = a.sc.has_tex != 0;
+#define RTW_LAUNCH_SHADING(K_, LDS_)                                                                              \
+    do {                                                                                                          \
+        if (lcg) { if (tex) hipLaunchKernelGGL((K_<RTW_RNG_TEA_LCG, true>), dim3(grid), dim3(kBlock), LDS_, s, a); \
+                   else hipLaunchKernelGGL((K_<RTW_RNG_TEA_LCG, false>), dim3(grid), dim3(kBlock), LDS_, s, a); }  \
+        else { if (tex) hipLaunchKernelGGL((K_<RTW_RNG_PHILOX, true>), dim3(grid), dim3(kBlock), LDS_, s, a);      \
+               else hipLaunchKernelGGL((K_<RTW_RNG_PHILOX, false>), dim3(grid), dim3(kBlock), LDS_, s, a); }       \
+    } while (0)
     switch (which) {
-    case LK_FIRST:
-        if (lcg) hipLaunchKernelGGL((k_first<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), lds, s, a);
-        else hipLaunchKernelGGL((k_first<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), lds, s, a);
-        break;
-    case LK_SHADE:
-        if (lcg) hipLaunchKernelGGL((k_shade<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), 0, s, a);
-        else hipLaunchKernelGGL((k_shade<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), 0, s, a);
-        break;
+    case LK_FIRST: RTW_LAUNCH_SHADING(k_first, lds); break;
+    case LK_SHADE: RTW_LAUNCH_SHADING(k_shade, 0); break;
     case LK_TRACE:
         if (a.sc.use_bvh) hipLaunchKernelGGL(k_trace_bvh, dim3(grid), dim3(kBlock), lds, s, a);
         else if (a.sc.n_generic == 0) hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(kBlock), lds, s, a);
         else hipLaunchKernelGGL((k_trace<false>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
-    default:
-        if (lcg) hipLaunchKernelGGL((k_bounce<RTW_RNG_TEA_LCG>), dim3(grid), dim3(kBlock), lds, s, a);
-        else hipLaunchKernelGGL((k_bounce<RTW_RNG_PHILOX>), dim3(grid), dim3(kBlock), lds, s, a);
-        break;
+    default: RTW_LAUNCH_SHADING(k_bounce, lds); break;
+#undef RTW_LAUNCH_SHADING
     }
 }
 
@@ -287,9 +288,33 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (h.n_textures) memcpy(texs.data(), b + h.off_textures, h.n_textures * sizeof(rtw_texture));
     if (h.n_lights) memcpy(lights.data(), b + h.off_lights, h.n_lights * sizeof(rtw_light));
 
+    // texture data section and texture records (same rules as the oracle's scene_open)
+    std::vector<uint32_t> texdata;
+    if (h.off_texdata) {
+        if ((h.off_texdata & 3u) || (size_t)h.off_texdata + (size_t)h.texdata_bytes > bytes) return fail(c, RTW_ERR_BAD_SCENE, "texture data section out of range");
+        texdata.resize(h.texdata_bytes / 4u);
+        if (!texdata.empty()) memcpy(texdata.data(), b + h.off_texdata, texdata.size() * 4u);
+    }
+    for (uint32_t i = 0; i < h.n_textures; i++) {
+        const rtw_texture& t = texs[i];
+        if (t.type == RTW_TEX_CHECKER) {
+            if (t.odd < 0 || t.even < 0 || (uint32_t)t.odd >= h.n_textures || (uint32_t)t.even >= h.n_textures ||
+                texs[t.odd].type == RTW_TEX_CHECKER || texs[t.even].type == RTW_TEX_CHECKER)
+                return fail(c, RTW_ERR_BAD_SCENE, "checker texture children out of range or nested");
+        } else if (t.type == RTW_TEX_NOISE) {
+            if ((size_t)t.data + 1536u > texdata.size()) return fail(c, RTW_ERR_BAD_SCENE, "noise texture tables out of range");
+        } else if (t.type == RTW_TEX_IMAGE) {
+            if ((size_t)t.data + 2u > texdata.size()) return fail(c, RTW_ERR_BAD_SCENE, "image texture out of range");
+            const uint32_t iw = texdata[t.data], ih = texdata[t.data + 1];
+            if (iw == 0 || ih == 0 || iw > 32768u || ih > 32768u || (size_t)t.data + 2u + (size_t)iw * ih > texdata.size())
+                return fail(c, RTW_ERR_BAD_SCENE, "image texture out of range");
+        } else if (t.type != RTW_TEX_CONSTANT && t.type != RTW_TEX_NULL) {
+            return fail(c, RTW_ERR_BAD_SCENE, "unknown texture type");
+        }
+    }
     std::vector<HitRec> shade(h.n_prims);
     std::vector<int32_t> order;
-    int has_motion = 0;
+    int has_motion = 0, has_tex = 0;
     for (uint32_t i = 0; i < h.n_prims; i++) {
         const rtw_prim& p = prims[i];
         if (p.type < RTW_PRIM_SPHERE || p.type > RTW_PRIM_VOLUME_SPHERE) return fail(c, RTW_ERR_BAD_SCENE, "unknown primitive type");
@@ -350,7 +375,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
             if ((uint32_t)m.texture >= h.n_textures) return fail(c, RTW_ERR_BAD_SCENE, "material texture out of range");
             const rtw_texture& t = texs[m.texture];
             if (t.type == RTW_TEX_CONSTANT) { s.r = t.color[0]; s.g = t.color[1]; s.b = t.color[2]; }
-            else if (t.type != RTW_TEX_NULL) return fail(c, RTW_ERR_UNSUPPORTED, "only constant and null textures are supported");
+            else if (t.type != RTW_TEX_NULL) { s.kind |= (m.texture + 1) << 8; has_tex = 1; }  // checker / noise / image: evaluated per hit
         }
         shade[i] = s;
     }
@@ -410,7 +435,9 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     size_t o_order = al(o_tree + std::max<size_t>(1, bvh.prim_order.size()) * sizeof(int32_t));
     size_t o_groups = al(o_order + std::max<size_t>(1, order.size()) * sizeof(int32_t));
     size_t o_recs = al(o_groups + std::max<size_t>(1, groups.size()) * sizeof(BruteGroup));
-    size_t total = al(o_recs + std::max<size_t>(1, recs.size()) * sizeof(BruteRec));
+    size_t o_texs = al(o_recs + std::max<size_t>(1, recs.size()) * sizeof(BruteRec));
+    size_t o_texdata = al(o_texs + std::max<size_t>(1, texs.size()) * sizeof(rtw_texture));
+    size_t total = al(o_texdata + std::max<size_t>(1, texdata.size()) * sizeof(uint32_t));
     std::vector<char> stage(total, 0);
     if (!prims.empty()) memcpy(stage.data() + o_prims, prims.data(), prims.size() * sizeof(rtw_prim));
     memcpy(stage.data() + o_xf, xforms.data(), xforms.size() * sizeof(rtw_xform));
@@ -422,6 +449,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!order.empty()) memcpy(stage.data() + o_order, order.data(), order.size() * sizeof(int32_t));
     if (!groups.empty()) memcpy(stage.data() + o_groups, groups.data(), groups.size() * sizeof(BruteGroup));
     if (!recs.empty()) memcpy(stage.data() + o_recs, recs.data(), recs.size() * sizeof(BruteRec));
+    if (!texs.empty()) memcpy(stage.data() + o_texs, texs.data(), texs.size() * sizeof(rtw_texture));
+    if (!texdata.empty()) memcpy(stage.data() + o_texdata, texdata.data(), texdata.size() * sizeof(uint32_t));
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -440,6 +469,9 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.order = (const int32_t*)(d + o_order);
     sc.groups = (const BruteGroup*)(d + o_groups);
     sc.recs = (const BruteRec*)(d + o_recs);
+    sc.texs = (const rtw_texture*)(d + o_texs);
+    sc.texdata = (const uint32_t*)(d + o_texdata);
+    sc.has_tex = has_tex;
     sc.n_groups = (int)groups.size();
     sc.n_generic = n_generic;
     sc.n_prims = (int)h.n_prims;

@@ -166,7 +166,7 @@ struct Nee {
 
 // Closest-hit / miss program up to and including the light sample (shaders/closehit.cu:45-94,
 // miss/miss.cu:8-30, material/*.cu, pdf/mixturePdf.cu:25-38, pdf/rectPdf.cu:124-193).
-template <int KIND>
+template <int KIND, bool TEX>
 RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 dir, const float gather_time, const float t, const int prim,
                     v3& so, v3& sd, v3& att, v3& radiance, Nee& nee) {
     radiance = V(0.f, 0.f, 0.f);
@@ -190,7 +190,8 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
     const int mtype = hr.mat_type;
     const float mparam = hr.param;
-    const v3 tex = V(hr.r, hr.g, hr.b);
+    v3 tex = V(hr.r, hr.g, hr.b);
+    if (TEX && hr.tex_dyn >= 0) tex = texture_eval(sc, hr, prim, origin, dir, t, 0.0f, hp, hn);  // checker / noise / image
     int ev;
     bool specular = false;
     if (mtype == RTW_MAT_LAMBERTIAN) {
@@ -464,7 +465,7 @@ RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, const TravMe
 }
 
 // ------------------------------------------------------------------ k_first
-template <int KIND>
+template <int KIND, bool TEX>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_CURSOR_SHARED
@@ -540,7 +541,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
                 traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
             v3 so, sd, att, radiance;
             Nee nee;
-            const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
+            const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
             n_seg++;
             if (nee.has) {
                 p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T);
@@ -755,7 +756,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
 #ifndef RTW_SHADE_WAVES
 #define RTW_SHADE_WAVES RTW_MIN_WAVES
 #endif
-template <int KIND>
+template <int KIND, bool TEX>
 __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A) {
     RTW_WORKLIST_SHARED
     RTW_CURSOR_SHARED
@@ -791,7 +792,7 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
                 const int prim = (int)(h.y & 0x3fffffffu) - 1;
                 v3 so, sd, att, radiance;
                 Nee nee;
-                const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, __uint_as_float(h.x), prim, so, sd, att, radiance, nee);
+                const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, __uint_as_float(h.x), prim, so, sd, att, radiance, nee);
                 n_seg++;
                 p.ltmax = -1.0f;
                 if (nee.has) {
@@ -819,7 +820,7 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
 }
 
 // ------------------------------------------------------------------ k_bounce (fused)
-template <int KIND>
+template <int KIND, bool TEX>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED
@@ -862,7 +863,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                     traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, g, tm, t, prim);
                     v3 so, sd, att, radiance;
                     Nee nee;
-                    const int ev = shade_a<KIND>(A.sc, g, p.o, p.d, gt, t, prim, so, sd, att, radiance, nee);
+                    const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, t, prim, so, sd, att, radiance, nee);
                     n_seg++;
                     if (nee.has) {
                         float st;

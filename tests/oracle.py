@@ -182,3 +182,80 @@ def random_scene(seed, w, h, n_prims=30, volumes=False, motion=False, n_lights=1
             add(abi.PRIM_VOLUME_SPHERE, (c[0], c[1], c[2], rs.uniform(40, 110), rs.uniform(0.002, 0.02)), i_iso, xf)
     parts.update(header=hdr, prims=prims, xforms=xforms, materials=materials, textures=textures, lights=lights)
     return abi.assemble_scene(parts)
+
+
+def perlin_tables(seed):
+    """ranvec[256][3] (unit vectors) + three permutations of 0..255, as the 1536 words rtw_texture.data points at."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    v = rs.uniform(-1, 1, (256, 3))
+    v = (v / np.linalg.norm(v, axis=1, keepdims=True)).astype("<f4")
+    perms = [rs.permutation(256).astype("<i4") for _ in range(3)]
+    return v.tobytes() + b"".join(p.tobytes() for p in perms)
+
+
+def test_image(w=64, h=32, seed=3):
+    """A small synthetic RGBA8 image (smooth gradients + blocks), as the words rtw_texture.data points at."""
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.zeros((h, w, 4), np.uint8)
+    img[..., 0] = (255 * x / (w - 1)).astype(np.uint8)
+    img[..., 1] = (255 * y / (h - 1)).astype(np.uint8)
+    img[..., 2] = rs.randint(0, 256, (h // 4, w // 4)).repeat(4, 0).repeat(4, 1)
+    img[..., 3] = 255
+    return np.array([w, h], "<u4").tobytes() + img.astype("<u1").tobytes()
+
+
+def textured_cornell(w, h, extra=0):
+    """Cornell box (reference scene 0) whose materials get the non-constant textures: Perlin noise on the floor
+    material, a checker of two constants on the back wall's, an image on the glass sphere's replacement (a Lambertian
+    sphere) and on the light-less ceiling rectangle, a checker of (noise, image) on the tall box. extra > 0 adds
+    spheres so that the tree path is used. Synthetic: exercises every texture callable and both u,v sources."""
+    import numpy as np
+    from raytracing_weekend_amd import abi
+    parts = dict(abi.parse_scene(abi.build_scene(0, w, h)))
+    prims, mats, texs = list(parts["prims"]), list(parts["materials"]), list(parts["textures"])
+    texdata = bytearray()
+
+    def blob_words(b):
+        off = len(texdata) // 4
+        texdata.extend(b)
+        return off
+
+    def add_tex(**kw):
+        t = abi.Texture(**{k: v for k, v in kw.items() if k != "color"})
+        if "color" in kw:
+            t.color[0], t.color[1], t.color[2] = kw["color"]
+        texs.append(t)
+        return len(texs) - 1
+    t_noise = add_tex(type=abi.TEX_NOISE, scale=0.05, data=blob_words(perlin_tables(1)))
+    t_noise2 = add_tex(type=abi.TEX_NOISE, scale=4.0, data=blob_words(perlin_tables(2)))
+    t_img = add_tex(type=abi.TEX_IMAGE, data=blob_words(test_image()))
+    t_a = add_tex(type=abi.TEX_CONSTANT, color=(0.9, 0.2, 0.1))
+    t_b = add_tex(type=abi.TEX_CONSTANT, color=(0.1, 0.2, 0.9))
+    t_chk = add_tex(type=abi.TEX_CHECKER, odd=t_a, even=t_b)
+    t_chk2 = add_tex(type=abi.TEX_CHECKER, odd=t_noise2, even=t_img)
+
+    def lambert(tex):
+        mats.append(abi.Material(type=abi.MAT_LAMBERTIAN, texture=tex, fuzz_or_eta=0.0, bsdf_eval=0))
+        return len(mats) - 1
+    m_noise, m_img, m_chk, m_chk2 = lambert(t_noise), lambert(t_img), lambert(t_chk), lambert(t_chk2)
+    mats.append(abi.Material(type=abi.MAT_METAL, texture=t_noise2, fuzz_or_eta=0.1, bsdf_eval=2))
+    m_metal_noise = len(mats) - 1
+    rects = [i for i, p in enumerate(prims) if abi.PRIM_RECT_X <= p.type <= abi.PRIM_RECT_Z and p.xform == 0 and mats[p.material].type == abi.MAT_LAMBERTIAN]
+    boxes = [i for i, p in enumerate(prims) if p.xform != 0]
+    spheres = [i for i, p in enumerate(prims) if p.type == abi.PRIM_SPHERE]
+    for k, i in enumerate(rects):
+        prims[i].material = (m_noise, m_chk, m_img, m_metal_noise, m_chk2)[k % 5]
+    for k, i in enumerate(boxes):
+        prims[i].material = (m_chk2, m_img, m_noise)[k % 3]
+    for i in spheres:
+        prims[i].material = m_img
+    rs = np.random.RandomState(5)
+    for k in range(extra):
+        pr = abi.Prim(type=abi.PRIM_SPHERE, material=(m_img, m_noise, m_chk, m_chk2)[k % 4], xform=0, flip=0)
+        pr.p[0], pr.p[1], pr.p[2], pr.p[3] = (float(rs.uniform(60, 495)), float(rs.uniform(40, 500)), float(rs.uniform(60, 495)), float(rs.uniform(12, 40)))
+        prims.append(pr)
+    parts.update(prims=prims, materials=mats, textures=texs, texdata=bytes(texdata))
+    return abi.assemble_scene(parts)

@@ -144,6 +144,45 @@ def test_random_scenes_sweep(gpu):
         assert np.array_equal(img, ref) and st.segments == st_ref.segments and st.shadow_rays == st_ref.shadow_rays, (seed, kw, w, h)
 
 
+@pytest.mark.parametrize("extra", [0, 40])
+def test_textured_scene_matches_oracle(gpu, extra):
+    """Checker, Perlin noise and image textures on rectangles, transformed boxes and spheres:
+    sin / atan2 / asin / floor, sphere and rectangle u,v, bilinear fetch - bit-exact against the oracle.
+    extra = 40 adds spheres so that the textured hits come out of the tree kernels."""
+    w, h = 112, 80
+    blob = oracle.textured_cornell(w, h, extra=extra)
+    gpu.upload_scene(blob)
+    for rng in (abi.RTW_RNG_PHILOX, abi.RTW_RNG_TEA_LCG):
+        for spp, depth in ((6, 30), (2, 3)):
+            p = abi.make_params(w, h, spp, depth, rng_kind=rng)
+            img, st = gpu.render(p)
+            ref, st_ref = oracle.render(blob, p, threads=16)
+            check(img, ref, st, st_ref)
+
+
+def test_textured_scene_through_the_fused_path(gpu):
+    """Same textures in a scene with volumes (every bounce in k_bounce)."""
+    w, h = 72, 72
+    parts = dict(abi.parse_scene(oracle.textured_cornell(w, h)))
+    fog = abi.parse_scene(abi.build_scene(3, w, h))
+    prims, mats, texs = list(parts["prims"]), list(parts["materials"]), list(parts["textures"])
+    vol = [p for p in fog["prims"] if p.type == abi.PRIM_VOLUME_BOX][0]
+    t = abi.Texture(type=abi.TEX_CONSTANT)
+    t.color[0] = t.color[1] = t.color[2] = 0.8
+    texs.append(t)
+    mats.append(abi.Material(type=abi.MAT_ISOTROPIC, texture=len(texs) - 1, fuzz_or_eta=0.0, bsdf_eval=-1))
+    v = abi.Prim.from_buffer_copy(bytes(vol))
+    v.material, v.xform = len(mats) - 1, 0
+    prims.append(v)
+    parts.update(prims=prims, materials=mats, textures=texs)
+    blob = abi.assemble_scene(parts)
+    gpu.upload_scene(blob)
+    p = abi.make_params(w, h, 5, 25)
+    img, st = gpu.render(p)
+    ref, st_ref = oracle.render(blob, p, threads=16)
+    check(img, ref, st, st_ref)
+
+
 def test_edge_cases(gpu):
     blob = abi.build_scene(0, 8, 8)
     gpu.upload_scene(blob)

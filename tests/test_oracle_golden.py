@@ -168,3 +168,48 @@ def test_schlick_and_power_heuristic_constants():
     assert math.isclose(r0, 0.04)
     a, b = 0.7, 0.2
     assert math.isclose(a * a / (a * a + b * b), 0.49 / 0.53)
+
+
+# ---------------------------------------------------------------- texture callables
+def test_spec_sin_atan2_asin_accuracy():
+    """The Cephes restatements the textures use stay within a few ulp of libm over the ranges the scenes produce."""
+    lib = oracle.load()
+    for f in ("rtwo_sinf", "rtwo_asinf"):
+        getattr(lib, f).restype = C.c_float
+        getattr(lib, f).argtypes = [C.c_float]
+    lib.rtwo_atan2f.restype = C.c_float
+    lib.rtwo_atan2f.argtypes = [C.c_float, C.c_float]
+    rs = np.random.RandomState(0)
+    xs = np.concatenate([rs.uniform(-6000, 6000, 4000), rs.uniform(-8, 8, 4000), [0.0, np.pi, -np.pi / 2]]).astype(np.float32)
+    assert max(abs(lib.rtwo_sinf(float(x)) - np.sin(np.float64(x))) for x in xs) < 2e-7
+    xs = np.concatenate([rs.uniform(-1, 1, 4000), [1.0, -1.0, 0.0, 0.5, 1.0000001, -1.5]]).astype(np.float32)
+    assert max(abs(lib.rtwo_asinf(float(x)) - np.arcsin(np.clip(np.float64(x), -1, 1))) for x in xs) < 4e-7
+    ys, xs = rs.uniform(-5, 5, 4000).astype(np.float32), rs.uniform(-5, 5, 4000).astype(np.float32)
+    assert max(abs(lib.rtwo_atan2f(float(y), float(x)) - np.arctan2(np.float64(y), np.float64(x))) for x, y in zip(xs, ys)) < 6e-7
+    assert lib.rtwo_atan2f(0.0, -1.0) == np.float32(np.pi) and lib.rtwo_atan2f(1.0, 0.0) == np.float32(np.pi / 2) and lib.rtwo_atan2f(0.0, 0.0) == 0.0
+
+
+def test_textured_scene_on_the_oracle():
+    """Checker / noise / image textures: finite image, textures visibly in effect, broken texture tables rejected."""
+    w, h = 48, 40
+    blob = oracle.textured_cornell(w, h)
+    p = abi.make_params(w, h, 3, 10)
+    img, st = oracle.render(blob, p, threads=4)
+    assert np.isfinite(img).all() and st.segments > 0
+    plain, _ = oracle.render(abi.build_scene(0, w, h), p, threads=4)
+    assert not np.array_equal(img, plain)
+    lib = oracle.load()
+    out = np.zeros((h, w, 4), np.float32)
+    st2 = abi.Stats()
+    parts = dict(abi.parse_scene(blob))
+    texs = list(parts["textures"])
+    noise = [i for i, t in enumerate(texs) if t.type == abi.TEX_NOISE][0]
+    bad = abi.Texture.from_buffer_copy(bytes(texs[noise]))
+    bad.data = len(parts["texdata"]) // 4 - 10  # tables would run past the section
+    texs[noise] = bad
+    parts["textures"] = texs
+    broken = abi.assemble_scene(parts)
+    assert lib.rtwo_render(broken, len(broken), C.byref(p), out.ctypes.data, C.byref(st2), 1) == -2
+    texs[noise] = abi.Texture(type=9)
+    broken = abi.assemble_scene(parts)
+    assert lib.rtwo_render(broken, len(broken), C.byref(p), out.ctypes.data, C.byref(st2), 1) == -2
