@@ -23,6 +23,8 @@ RTW_RNG_TEA_LCG = 1
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_RECT_X, PRIM_RECT_Y, PRIM_RECT_Z, PRIM_VOLUME_BOX, PRIM_VOLUME_SPHERE = range(7)
 # rtw_material_type
 MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_METAL, MAT_DIELECTRIC, MAT_ISOTROPIC, MAT_NORMAL = range(6)
+# rtw_pdf_gen
+RTW_PDF_COSINE, RTW_PDF_MIXTURE_BIAS, RTW_PDF_MIXTURE, RTW_PDF_RECT_X, RTW_PDF_RECT_Y, RTW_PDF_RECT_Z = range(6)
 # rtw_texture_type
 TEX_CHECKER, TEX_CONSTANT, TEX_IMAGE, TEX_NOISE, TEX_NULL = range(5)
 

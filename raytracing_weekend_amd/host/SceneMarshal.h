@@ -18,7 +18,7 @@ inline std::vector<uint8_t> marshalScene(const ioScene& sc) {
     std::vector<rtw_prim> prims;
     std::vector<rtw_xform> xforms;
     std::vector<rtw_material> mats;
-    std::vector<rtw_texture> texs;
+    TexEmit emit;  // texture records + texture data section, in material-list order (Director.cpp:503-513)
 
     rtw_xform ident{};
     ident.m[0] = ident.m[5] = ident.m[10] = 1.f;
@@ -30,10 +30,7 @@ inline std::vector<uint8_t> marshalScene(const ioScene& sc) {
         rtw_material m{};
         m.texture = -1;
         const ioTexture* t = sc.materialList[i]->assignTo(m);
-        if (t) {
-            m.texture = static_cast<int32_t>(texs.size());
-            texs.push_back(t->getTexRec());
-        }
+        if (t) m.texture = t->emit(emit);
         mats.push_back(m);
     }
 
@@ -64,6 +61,7 @@ inline std::vector<uint8_t> marshalScene(const ioScene& sc) {
     h.n_prims = static_cast<uint32_t>(prims.size());
     h.n_xforms = static_cast<uint32_t>(xforms.size());
     h.n_materials = static_cast<uint32_t>(mats.size());
+    const std::vector<rtw_texture>& texs = emit.texs;
     h.n_textures = static_cast<uint32_t>(texs.size());
     h.n_lights = static_cast<uint32_t>(sc.m_lightDefinitions.size());
     h.sky_light = sc.m_lightDefinitions.empty() ? 1 : 0;  // Director.cpp:523
@@ -90,6 +88,11 @@ inline std::vector<uint8_t> marshalScene(const ioScene& sc) {
     h.off_materials = static_cast<uint32_t>(off); off = align16(off + mats.size() * sizeof(rtw_material));
     h.off_textures = static_cast<uint32_t>(off); off = align16(off + texs.size() * sizeof(rtw_texture));
     h.off_lights = static_cast<uint32_t>(off); off = align16(off + sc.m_lightDefinitions.size() * sizeof(rtw_light));
+    if (!emit.data.empty()) {  // texture data section (noise tables, image texels); absent for constant-only scenes
+        h.off_texdata = static_cast<uint32_t>(off);
+        h.texdata_bytes = static_cast<uint32_t>(emit.data.size() * sizeof(uint32_t));
+        off = align16(off + h.texdata_bytes);
+    }
     h.total_bytes = static_cast<uint32_t>(off);
 
     std::vector<uint8_t> blob(off, 0);
@@ -100,6 +103,7 @@ inline std::vector<uint8_t> marshalScene(const ioScene& sc) {
     if (!texs.empty()) memcpy(blob.data() + h.off_textures, texs.data(), texs.size() * sizeof(rtw_texture));
     if (!sc.m_lightDefinitions.empty())
         memcpy(blob.data() + h.off_lights, sc.m_lightDefinitions.data(), sc.m_lightDefinitions.size() * sizeof(rtw_light));
+    if (!emit.data.empty()) memcpy(blob.data() + h.off_texdata, emit.data.data(), h.texdata_bytes);
     return blob;
 }
 

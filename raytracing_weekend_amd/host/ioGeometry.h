@@ -3,7 +3,14 @@
 // but every class only fills the pointer-free records of include/rtw.h; there is no OptiX
 // accel build here (the library builds its own BVH in rtw_upload_scene).
 #pragma once
+#include <cctype>
+#include <cmath>
+#include <cstring>
+#include <fstream>
 #include <memory>
+#include <random>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "../../include/rtw.h"
@@ -95,27 +102,146 @@ public:
     float cx, cy, cz, r, density;
 };
 
-// ---------------------------------------------------------------- textures (texture/ioTexture.h:28-86)
+// ---------------------------------------------------------------- textures (texture/ioTexture.h:28-338)
+// What getTexRec() hands to the device in the reference (a textureParam with device pointers) becomes a record in
+// textures[] plus, for noise and image textures, words in the blob's texture data section.
+struct TexEmit {
+    std::vector<rtw_texture> texs;
+    std::vector<uint32_t> data;
+    // ioTexture.h:21-26 localRnd(): one mt19937(0) shared by every noise texture of the scene, drawn in the order
+    // the material list reaches them. std::uniform_real_distribution<float> is not specified bit for bit across
+    // standard libraries: this is libstdc++'s, the reference was only ever built with MSVC's (tables unpinned).
+    std::mt19937 gen{0};
+    std::uniform_real_distribution<float> dis{0.f, 1.f};
+    float localRnd() { return dis(gen); }
+};
+
 struct ioTexture {
     virtual ~ioTexture() {}
-    virtual rtw_texture getTexRec() const = 0;
+    // appends this texture's record (and whatever it refers to) and returns the record's index in e.texs
+    virtual int32_t emit(TexEmit& e) const = 0;
 };
 struct ioNullTexture : ioTexture {
-    rtw_texture getTexRec() const override {
+    int32_t emit(TexEmit& e) const override {
         rtw_texture t{};
         t.type = RTW_TEX_NULL;
-        return t;
+        e.texs.push_back(t);
+        return static_cast<int32_t>(e.texs.size()) - 1;
     }
 };
 struct ioConstantTexture : ioTexture {
     explicit ioConstantTexture(const Float3& c) : color(c) {}
-    rtw_texture getTexRec() const override {
+    int32_t emit(TexEmit& e) const override {
         rtw_texture t{};
         t.type = RTW_TEX_CONSTANT;
         t.color[0] = color.x; t.color[1] = color.y; t.color[2] = color.z;
-        return t;
+        e.texs.push_back(t);
+        return static_cast<int32_t>(e.texs.size()) - 1;
     }
     Float3 color;
+};
+// ioTexture.h:88-116. The reference stores the children's callable ids (par.odd = odd->texIdx), so its checker
+// only ever evaluates constant colours of an empty record; here the children are emitted and evaluated.
+struct ioCheckerTexture : ioTexture {
+    ioCheckerTexture(const ioTexture* o, const ioTexture* e) : odd(o), even(e) {}
+    int32_t emit(TexEmit& e) const override {
+        rtw_texture t{};
+        t.type = RTW_TEX_CHECKER;
+        t.odd = odd->emit(e);
+        t.even = even->emit(e);
+        e.texs.push_back(t);
+        return static_cast<int32_t>(e.texs.size()) - 1;
+    }
+    const ioTexture* odd;
+    const ioTexture* even;
+};
+// ioTexture.h:118-222: Perlin gradient table and three permutations, generated when the record is requested
+struct ioNoiseTexture : ioTexture {
+    explicit ioNoiseTexture(float s) : scale(s) {}
+    int32_t emit(TexEmit& e) const override {
+        rtw_texture t{};
+        t.type = RTW_TEX_NOISE;
+        t.scale = scale;
+        t.data = static_cast<uint32_t>(e.data.size());
+        auto putf = [&](float f) { uint32_t u; memcpy(&u, &f, 4); e.data.push_back(u); };
+        for (int i = 0; i < 256; i++) {
+            // unit_float3(-1 + 2*localRnd(), -1 + 2*localRnd(), -1 + 2*localRnd()): argument order as MSVC (Q6)
+            float z = -1 + 2 * e.localRnd();
+            float y = -1 + 2 * e.localRnd();
+            float x = -1 + 2 * e.localRnd();
+            float l = sqrtf(x * x + y * y + z * z);
+            putf(x / l); putf(y / l); putf(z / l);
+        }
+        for (int k = 0; k < 3; k++) {  // perm_x, perm_y, perm_z (ioTexture.h:128-149)
+            int p[256];
+            for (int i = 0; i < 256; i++) p[i] = i;
+            for (int i = 256 - 1; i > 0; i--) {
+                int target = int(e.localRnd() * (i + 1));
+                int tmp = p[i]; p[i] = p[target]; p[target] = tmp;
+            }
+            for (int i = 0; i < 256; i++) e.data.push_back(static_cast<uint32_t>(p[i]));
+        }
+        e.texs.push_back(t);
+        return static_cast<int32_t>(e.texs.size()) - 1;
+    }
+    float scale;
+};
+// ioTexture.h:225-338. The reference decodes assets/earthmap.jpg with stb_image; this host reads binary or ASCII
+// PPM (P6 / P3, 8 bit) and nothing else. Rows are flipped like ioTexture.h:247-250, alpha is 255.
+struct ioImageTexture : ioTexture {
+    explicit ioImageTexture(const std::string& fileName) { load(fileName); }
+    int32_t emit(TexEmit& e) const override {
+        rtw_texture t{};
+        t.type = RTW_TEX_IMAGE;
+        t.data = static_cast<uint32_t>(e.data.size());
+        e.data.push_back(static_cast<uint32_t>(nx));
+        e.data.push_back(static_cast<uint32_t>(ny));
+        e.data.insert(e.data.end(), texels.begin(), texels.end());
+        e.texs.push_back(t);
+        return static_cast<int32_t>(e.texs.size()) - 1;
+    }
+    int nx = 0, ny = 0;
+    std::vector<uint32_t> texels;
+
+private:
+    void load(const std::string& fileName) {
+        std::ifstream f(fileName, std::ios::binary);
+        if (!f) throw std::runtime_error("image texture: cannot open " + fileName);
+        auto token = [&]() {  // PNM header token, '#' comments skipped
+            std::string tok;
+            int ch;
+            while ((ch = f.get()) != EOF) {
+                if (ch == '#') { while ((ch = f.get()) != EOF && ch != '\n') {} continue; }
+                if (isspace(ch)) { if (!tok.empty()) break; continue; }
+                tok.push_back(static_cast<char>(ch));
+            }
+            return tok;
+        };
+        const std::string magic = token();
+        if (magic != "P6" && magic != "P3") throw std::runtime_error("image texture: " + fileName + " is not a P6/P3 PPM");
+        int maxv = 0;
+        try { nx = std::stoi(token()); ny = std::stoi(token()); maxv = std::stoi(token()); }
+        catch (const std::exception&) { throw std::runtime_error("image texture: bad PPM header in " + fileName); }
+        if (nx <= 0 || ny <= 0 || nx > 32768 || ny > 32768 || maxv != 255) throw std::runtime_error("image texture: unsupported PPM (size or maxval) " + fileName);
+        std::vector<unsigned char> rgb(static_cast<size_t>(nx) * ny * 3);
+        if (magic == "P6") {
+            f.read(reinterpret_cast<char*>(rgb.data()), static_cast<std::streamsize>(rgb.size()));
+            if (static_cast<size_t>(f.gcount()) != rgb.size()) throw std::runtime_error("image texture: truncated PPM " + fileName);
+        } else {
+            for (size_t i = 0; i < rgb.size(); i++) {
+                const std::string t = token();
+                if (t.empty()) throw std::runtime_error("image texture: truncated PPM " + fileName);
+                rgb[i] = static_cast<unsigned char>(std::stoi(t));
+            }
+        }
+        texels.resize(static_cast<size_t>(nx) * ny);
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < ny; ++j) {
+                const size_t bindex = static_cast<size_t>(j) * nx + i;
+                const size_t iindex = (static_cast<size_t>(ny - j - 1) * nx + i) * 3;
+                texels[bindex] = rgb[iindex] | (uint32_t(rgb[iindex + 1]) << 8) | (uint32_t(rgb[iindex + 2]) << 16) | (255u << 24);
+            }
+    }
 };
 
 // ---------------------------------------------------------------- materials (material/io*Material.h)

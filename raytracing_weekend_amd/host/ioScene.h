@@ -1,12 +1,19 @@
 // ioScene.h — the hard-coded scenes, as in the reference's scene/ioScene.h:
 //   0 CornellBox          (ioScene.h:491-627)   metric scene
 //   1 MovingSpheres       (ioScene.h:180-309)   "In One Weekend" final scene, 70% moving spheres
+//   2 InOneWeekendLight   (ioScene.h:313-489)   static spheres, Perlin ground, earth-map sphere, one rectangle light
 //   3 VolumesCornellBox   (ioScene.h:630-788)   Cornell box with two participating media
-// Scenes 2 and 4 need checker / noise / image textures (next) and are rejected.
+//   4 TheNextWeekFinal    (ioScene.h:791-982)   400 ground boxes, 1000-sphere cluster under a transform, two media,
+//                                               noise / image textures, a moving sphere (3410 primitives)
+// Scenes 2 and 4 load assets/earthmap.ppm (see assetPath); the reference decodes assets/earthmap.jpg with stb_image.
 // Primitive i, material i and instance i line up, as the reference relies on
 // (geometryList.size()==materialList.size(), ioScene.h:262,426,581).
 #pragma once
+#include <dlfcn.h>
+
 #include <cstdint>
+#include <cstdlib>
+#include <fstream>
 #include <iostream>
 #include <memory>
 #include <string>
@@ -39,19 +46,46 @@ struct pdfCallfun_host {
     float bias = 0.f;
 };
 
+// Where an asset of the reference's assets/ directory is looked for: $RTW_ASSET_DIR, ./assets (the reference's
+// relative path), then assets/ next to the binary this code is linked into (librtw_host.so or rtw_render).
+inline std::string assetPath(const std::string& name) {
+    std::vector<std::string> dirs;
+    if (const char* e = getenv("RTW_ASSET_DIR")) dirs.push_back(e);
+    dirs.push_back("assets");
+    Dl_info info;
+    if (dladdr(reinterpret_cast<const void*>(&xorshift32), &info) && info.dli_fname) {
+        std::string self(info.dli_fname);
+        const size_t slash = self.find_last_of('/');
+        dirs.push_back((slash == std::string::npos ? std::string(".") : self.substr(0, slash)) + "/assets");
+    }
+    for (const std::string& d : dirs) {
+        const std::string p = d + "/" + name;
+        if (std::ifstream(p).good()) return p;
+    }
+    return dirs.back() + "/" + name;  // reported in the error message of the loader
+}
+
 class ioScene {
 public:
-    // returns non-zero for an unknown scene, like ioScene::init (ioScene.h:52-101)
+    // returns non-zero for an unknown scene, like ioScene::init (ioScene.h:52-101), and when an asset is missing
     int init(int Nx, int Ny, int Ns, int maxRayDepth, int Nscene) {
         m_Nx = Nx; m_Ny = Ny; m_numSamples = Ns; m_maxRayDepth = maxRayDepth;
         destroy();
         if (getScenePdf(Nscene)) return 1;
-        switch (Nscene) {
-        case 0: CornellBox(); break;
-        case 1: MovingSpheres(); break;
-        case 3: VolumesCornellBox(); break;
-        default:
-            std::cerr << "ERROR: Scene " << Nscene << " unknown." << std::endl;
+        try {
+            switch (Nscene) {
+            case 0: CornellBox(); break;
+            case 1: MovingSpheres(); break;
+            case 2: InOneWeekendLight(); break;
+            case 3: VolumesCornellBox(); break;
+            case 4: TheNextWeekFinal(); break;
+            default:
+                std::cerr << "ERROR: Scene " << Nscene << " unknown." << std::endl;
+                return 1;
+            }
+        } catch (const std::exception& ex) {  // the reference dereferences stbi_load's null result instead
+            std::cerr << "ERROR: " << ex.what() << std::endl;
+            destroy();
             return 1;
         }
         return 0;
@@ -83,9 +117,17 @@ private:
         case 1:
             MCpdf.pdfGenIdx = RTW_PDF_COSINE;
             return 0;
+        case 2:  // note the rectangle the pdf samples (y 2.3..6) is not the light's (y 1..3): ioScene.h:121-127
+            MCpdf.pdfGenIdx = RTW_PDF_MIXTURE; MCpdf.p0GenIdx = RTW_PDF_COSINE; MCpdf.p1GenIdx = RTW_PDF_RECT_Z;
+            setRect(3.f, 5.f, 2.3f, 3.f + 3.f, -2.0f);
+            return 0;
         case 3:
             MCpdf.pdfGenIdx = RTW_PDF_MIXTURE; MCpdf.p0GenIdx = RTW_PDF_COSINE; MCpdf.p1GenIdx = RTW_PDF_RECT_Y;
             setRect(213.f, 343.f, 227.f, 332.f, 554.f);
+            return 0;
+        case 4:
+            MCpdf.pdfGenIdx = RTW_PDF_MIXTURE; MCpdf.p0GenIdx = RTW_PDF_COSINE; MCpdf.p1GenIdx = RTW_PDF_RECT_Y;
+            setRect(123.f, 423.f, 147.f, 412.f, 554.f);
             return 0;
         default:
             std::cerr << "ERROR: Scene " << Nscene << " unknown." << std::endl;
@@ -212,6 +254,157 @@ private:
         camera.reset(new ioPerspectiveCamera(13.0f, 2.0f, 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 20.0f,
                                              float(m_Nx) / float(m_Ny), /*aperture*/ 0.1f, /*focus_distance*/ 10.f, 0.f, 1.f));
         // no light definition: the sky lights the scene (Director.cpp:523-524)
+    }
+
+    void rectLight(const Float3& pos, const Float3& U, const Float3& V, const Float3& emission) {
+        rtw_light light{};
+        light.emission[0] = emission.x; light.emission[1] = emission.y; light.emission[2] = emission.z;
+        light.vec_u[0] = U.x; light.vec_u[1] = U.y; light.vec_u[2] = U.z;
+        light.vec_v[0] = V.x; light.vec_v[1] = V.y; light.vec_v[2] = V.z;
+        light.position[0] = pos.x; light.position[1] = pos.y; light.position[2] = pos.z;
+        Float3 c = cross(U, V);
+        Float3 n = normalize(c);
+        light.area = length(c);
+        light.normal[0] = n.x; light.normal[1] = n.y; light.normal[2] = n.z;
+        m_lightDefinitions.push_back(light);
+    }
+
+    // ---------------------------------------------------------------- scene 2
+    void InOneWeekendLight() {
+        sceneDescription = "IOW Scene with a light box";
+        const ioTexture* constantGrey = tex(new ioConstantTexture(make_float3(0.7f, 0.7f, 0.7f)));
+        const ioTexture* noise1 = tex(new ioNoiseTexture(1.f));
+        const ioTexture* earthGlobeImage = tex(new ioImageTexture(assetPath("earthmap.ppm")));
+        const ioTexture* light16 = tex(new ioConstantTexture(make_float3(16.f, 16.f, 16.f)));
+
+        geometryList.emplace_back(new ioSphere(0.0f, -1000.0f, 0.0f, 1000.0f));  // big sphere, Perlin ground
+        materialList.push_back(mat(new ioLambertianMaterial(noise1)));
+        geometryList.emplace_back(new ioSphere(-4.0f, 1.0f, 0.0f, 1.0f));
+        geometryList.emplace_back(new ioSphere(0.0f, 1.0f, 0.0f, 1.0f));
+        geometryList.emplace_back(new ioSphere(4.0f, 1.0f, 0.0f, 1.0f));
+        materialList.push_back(mat(new ioMetalMaterial(constantGrey, 0.4f)));
+        materialList.push_back(mat(new ioLambertianMaterial(earthGlobeImage)));
+        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+        geometryList.emplace_back(new ioAARect(3.f, 5.f, 1.f, 3.f, -2.0f, false, Z_AXIS));
+        materialList.push_back(mat(new ioDiffuseLightMaterial(light16)));
+        rectLight(make_float3(3.f, 1.f, -2.f), make_float3(5.f - 3.f, 0.f, 0.f), make_float3(0.f, 3.f - 1.f, 0.f), make_float3(16.f, 16.f, 16.f));
+
+        // small spheres, ioScene.h:373-422 (argument evaluation order as in scene 1: right to left, MSVC)
+        uint32_t seed = 0x6314759;
+        for (int a = -11; a < 11; a++) {
+            for (int b = -11; b < 11; b++) {
+                float chooseMat = randf(seed);
+                float x = a + 0.8f * randf(seed);
+                float y = 0.2f;
+                float z = b + 0.9f * randf(seed);
+                float z_squared = z * z;
+                float dist = sqrtf((x - 4.0f) * (x - 4.0f) + z_squared);
+                if ((dist > 0.9f) || ((z_squared > 0.7f) && ((x * x - 16.0f) > -2.f))) {
+                    if (chooseMat < 0.70f) {
+                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
+                        float cb = randf(seed), cg = randf(seed), cr = randf(seed);
+                        materialList.push_back(mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))))));
+                    } else if (chooseMat < 0.85f) {
+                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
+                        float fuzz = 0.5f * randf(seed);
+                        float cb = 0.5f * (1.0f - randf(seed));
+                        float cg = 0.5f * (1.0f - randf(seed));
+                        float cr = 0.5f * (1.0f - randf(seed));
+                        materialList.push_back(mat(new ioMetalMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))), fuzz)));
+                    } else if (chooseMat < 0.93f) {
+                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
+                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+                    } else {
+                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
+                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+                        geometryList.emplace_back(new ioSphere(x, y, z, (0.2f - 0.007f)));
+                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+                    }
+                }
+            }
+        }
+        identityInstances();
+        camera.reset(new ioPerspectiveCamera(13.0f, 2.0f, 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 20.0f,
+                                             float(m_Nx) / float(m_Ny), /*aperture*/ 0.08f, /*focus_distance*/ 10.f));
+    }
+
+    // ---------------------------------------------------------------- scene 4
+    void TheNextWeekFinal() {
+        sceneDescription = "The Next Week final scene";
+        const ioTexture* brown = tex(new ioConstantTexture(make_float3(0.7f, 0.3f, 0.1f)));
+        const ioTexture* groundGreenish = tex(new ioConstantTexture(make_float3(0.48f, 0.83f, 0.53f)));
+        const ioTexture* metal1 = tex(new ioConstantTexture(make_float3(0.8f, 0.8f, 0.9f)));
+        const ioTexture* noisep1 = tex(new ioNoiseTexture(0.1f));
+        const ioTexture* earthGlobeImage = tex(new ioImageTexture(assetPath("earthmap.ppm")));
+        const ioTexture* light7 = tex(new ioConstantTexture(make_float3(7.f, 7.f, 7.f)));
+        uint32_t seed = 0x6314759;
+        const ioMaterial* glassyBlueFog = mat(new ioIsotropicMaterial(tex(new ioConstantTexture(make_float3(0.2f, 0.4f, 0.9f)))));
+        const ioMaterial* ambientFog = mat(new ioIsotropicMaterial(tex(new ioConstantTexture(make_float3(0.95f)))));
+        const ioMaterial* ground = mat(new ioLambertianMaterial(groundGreenish));
+
+        // instance id = material index, one geometry per instance; the order below is the order of the reference's
+        // instance list (geoInstList, then the two media, then the sphere cluster: ioScene.h:947-955)
+        auto instance = [&](const ioMaterial* m) -> ioGeometryInstance& {
+            materialList.push_back(m);
+            geoInstList.emplace_back();
+            geoInstList.back().init(static_cast<unsigned>(materialList.size() - 1), static_cast<unsigned>(geometryList.size() - 1));
+            return geoInstList.back();
+        };
+        geometryList.emplace_back(new ioAARect(123.f, 423.f, 147.f, 412.f, 554.f, true, Y_AXIS));  // light
+        instance(mat(new ioDiffuseLightMaterial(light7)));
+        rectLight(make_float3(123.f, 554.f, 147.f), make_float3(423.f - 123.f, 0.f, 0.f), make_float3(0.f, 0.f, 412.f - 147.f), make_float3(7.f, 7.f, 7.f));
+        Float3 center = make_float3(400.f, 400.f, 200.f);
+        Float3 center1tr = center + make_float3(30.f, 0.f, 0.f);
+        geometryList.emplace_back(new ioSphere(260.f, 150.f, 45.f, 50.f));  // glass sphere
+        instance(mat(new ioDielectricMaterial(1.5f)));
+        geometryList.emplace_back(new ioSphere(0.f, 150.f, 145.f, 50.f));   // metal sphere
+        instance(mat(new ioMetalMaterial(metal1, 0.2f)));
+        Float3 centerGlassy = make_float3(360.f, 150.f, 45.f);
+        geometryList.emplace_back(new ioSphere(centerGlassy.x, centerGlassy.y, centerGlassy.z, 70.f));  // blue glassy sphere (holds a medium)
+        instance(mat(new ioDielectricMaterial(1.5f)));
+        geometryList.emplace_back(new ioSphere(0.f, 0.f, 0.f, 5000.f));     // room boundary
+        instance(mat(new ioDielectricMaterial(1.5f)));
+        geometryList.emplace_back(new ioSphere(400.f, 200.f, 400.f, 100.0f));  // earth globe
+        instance(mat(new ioLambertianMaterial(earthGlobeImage)));
+        geometryList.emplace_back(new ioSphere(220.f, 280.f, 300.f, 80.f));    // marble
+        instance(mat(new ioLambertianMaterial(noisep1)));
+        geometryList.emplace_back(new ioMovingSphere(center.x, center.y, center.z, center1tr.x, center1tr.y, center1tr.z, 50.f, 0.f, 1.f));
+        instance(mat(new ioLambertianMaterial(brown)));
+
+        // ground: 20 x 20 boxes of random height, six rectangles each (ioScene.h:886-918)
+        for (int i = 0; i < 20; i++) {
+            for (int j = 0; j < 20; j++) {
+                float w = 100.f;
+                float x0 = -1000 + i * w;
+                float z0 = -1000 + j * w;
+                float y0 = 0.f;
+                float x1 = x0 + w;
+                float y1 = 100 * (randf(seed) + 0.01f);
+                float z1 = z0 + w;
+                std::vector<std::unique_ptr<ioGeometry>> box;
+                ioGeometryGroup::createBox(make_float3(x0, y0, z0), make_float3(x1, y1, z1), box);
+                for (auto& r : box) {
+                    geometryList.emplace_back(std::move(r));
+                    instance(ground);
+                }
+            }
+        }
+        // the two media (ioScene.h:920-929)
+        geometryList.emplace_back(new ioVolumeSphere(centerGlassy.x, centerGlassy.y, centerGlassy.z, 70.f, 0.2f));
+        instance(glassyBlueFog);
+        geometryList.emplace_back(new ioVolumeSphere(0.f, 0.f, 0.f, 500.f, 8e-5f));
+        instance(ambientFog);
+        // 1000 small spheres in a 165-cube, moved as a block: T(-100,270,395) * R_y(20 deg) (ioScene.h:931-945)
+        const ioMaterial* white = mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(0.93f)))));
+        Mat4 transmat = ioTransform::translate(make_float3(-100.f, 270.f, 395.f));
+        transmat *= ioTransform::rotateY(20.f);
+        for (int j = 0; j < 1000; j++) {
+            float cz = 165 * randf(seed), cy = 165 * randf(seed), cx = 165 * randf(seed);  // right to left (Q6)
+            geometryList.emplace_back(new ioSphere(cx, cy, cz, 10.f));
+            instance(white).setTransform(transmat);
+        }
+        camera.reset(new ioPerspectiveCamera(478.f, 278.f, -600.f, 278.f, 278.f, 0.f, 0.f, 1.f, 0.f, 40.0f,
+                                             float(m_Nx) / float(m_Ny), /*aperture*/ 0.1f, /*focus_distance*/ 10.f, 0.f, 1.f));
     }
 
     // ---------------------------------------------------------------- scene 3

@@ -49,7 +49,8 @@ int main(int argc, char* argv[]) {
     if (cl_input.cmdOptionExists("-h") || cl_input.cmdOptionExists("--help")) {
         std::cerr << "\n HELP - " << argv[0] << "\n"
                   << R"(
-    -s N           Scene Selection number N (0 Cornell box, 1 moving spheres, 3 Cornell box with volumes)
+    -s N           Scene Selection number N (0 Cornell box, 1 moving spheres, 2 spheres with a light,
+                   3 Cornell box with volumes, 4 The Next Week final scene)
     -ns N          Sample each pixel N times (N: 1, 2, etc.)
     -dx Nx         Output image width (x dimension)
     -dy Ny         Output image height (y dimension)

@@ -58,6 +58,20 @@ def test_matches_golden_fixture(gpu, name):
     assert st.algorithmic_bytes == 128 * st.segments + 32 * st.samples
 
 
+@pytest.mark.parametrize("rng", [abi.RTW_RNG_PHILOX, abi.RTW_RNG_TEA_LCG])
+@pytest.mark.parametrize("scene,w,h,spp,depth", [
+    (2, 128, 72, 6, 30),   # 520 static spheres, Perlin ground, image-textured sphere, rectangle light: tree + split pipeline
+    (4, 112, 64, 4, 30),   # 3410 primitives: ground boxes, transformed sphere cluster, two media, motion: tree + fused path
+])
+def test_textured_reference_scenes_match_oracle(gpu, scene, w, h, spp, depth, rng):
+    blob = abi.build_scene(scene, w, h)
+    p = abi.make_params(w, h, spp, depth, rng_kind=rng)
+    gpu.upload_scene(blob)
+    img, st = gpu.render(p)
+    ref, st_ref = oracle.render(blob, p, threads=16)
+    check(img, ref, st, st_ref)
+
+
 @pytest.mark.parametrize("scene,w,h,spp,depth", [
     (0, 160, 120, 8, 50),    # Cornell box, deep paths: NEE, metal box under a transform, glass sphere, RR
     (0, 33, 17, 3, 7),       # ragged sizes: last chunk / last region partially filled

@@ -89,9 +89,56 @@ def test_volumes_scene():
 
 
 def test_unknown_scene_is_rejected():
-    for bad in (2, 4, 5, -1):  # 2 and 4 need checker/noise/image textures: out of scope this round
+    for bad in (5, 17, -1):
         with pytest.raises(ValueError):
             abi.build_scene(bad, 64, 64)
+
+
+def test_textured_scenes_2_and_4():
+    """Scene 2 (ioScene.h:313-489) and scene 4 (ioScene.h:791-982): structure of the blobs the host builds."""
+    s2 = abi.parse_scene(abi.build_scene(2, 64, 48))
+    h = s2["header"]
+    assert h.n_lights == 1 and h.sky_light == 0 and h.pdf.gen == abi.RTW_PDF_MIXTURE and h.pdf.p1_gen == abi.RTW_PDF_RECT_Z
+    assert [round(v, 4) for v in h.pdf.rect] == [3.0, 5.0, 2.3, 6.0, -2.0]
+    prims, mats, texs = s2["prims"], s2["materials"], s2["textures"]
+    assert h.n_prims == h.n_materials and prims[0].type == abi.PRIM_SPHERE and prims[4].type == abi.PRIM_RECT_Z
+    assert texs[mats[0].texture].type == abi.TEX_NOISE and texs[mats[0].texture].scale == 1.0
+    assert texs[mats[2].texture].type == abi.TEX_IMAGE and mats[3].type == abi.MAT_DIELECTRIC and mats[4].type == abi.MAT_DIFFUSE_LIGHT
+    assert all(p.xform == 0 and p.type == abi.PRIM_SPHERE for p in list(prims)[5:])
+    words = np.frombuffer(s2["texdata"], "<u4")
+    img = texs[mats[2].texture].data
+    assert words[img] == 512 and words[img + 1] == 256 and len(words) == 1536 + 2 + 512 * 256
+    tab = texs[mats[0].texture].data
+    ranvec = words[tab:tab + 768].view("<f4").reshape(256, 3)
+    assert np.allclose(np.linalg.norm(ranvec, axis=1), 1.0, atol=1e-6)
+    for k in range(3):
+        assert sorted(words[tab + 768 + 256 * k: tab + 1024 + 256 * k].view("<i4")) == list(range(256))
+
+    s4 = abi.parse_scene(abi.build_scene(4, 64, 48))
+    h = s4["header"]
+    prims, mats, texs = list(s4["prims"]), s4["materials"], s4["textures"]
+    assert h.n_prims == 8 + 2400 + 2 + 1000 and h.n_xforms == 2 and h.n_lights == 1 and h.pdf.p1_gen == abi.RTW_PDF_RECT_Y
+    assert prims[0].type == abi.PRIM_RECT_Y and prims[0].flip == 1 and mats[prims[0].material].type == abi.MAT_DIFFUSE_LIGHT
+    assert prims[7].type == abi.PRIM_MOVING_SPHERE and texs[mats[5].texture].type == abi.TEX_IMAGE and texs[mats[6].texture].type == abi.TEX_NOISE
+    assert all(abi.PRIM_RECT_X <= p.type <= abi.PRIM_RECT_Z and p.xform == 0 for p in prims[8:2408])
+    assert [p.type for p in prims[2408:2410]] == [abi.PRIM_VOLUME_SPHERE] * 2 and all(mats[p.material].type == abi.MAT_ISOTROPIC for p in prims[2408:2410])
+    assert all(p.type == abi.PRIM_SPHERE and p.xform == 1 and p.p[3] == 10.0 for p in prims[2410:])
+    assert all(p.material == i for i, p in enumerate(prims))
+    m = np.array(s4["xforms"][1].m[:]).reshape(3, 4)
+    c, s_ = np.cos(np.deg2rad(20.0)), np.sin(np.deg2rad(20.0))
+    assert np.allclose(m, [[c, 0, s_, -100], [0, 1, 0, 270], [-s_, 0, c, 395]], atol=1e-5)
+
+
+def test_asset_dir_override(tmp_path, monkeypatch):
+    """RTW_ASSET_DIR replaces the shipped synthetic earth map (P3 and P6 are both read; rows are flipped on load)."""
+    (tmp_path / "earthmap.ppm").write_text("P3\n# tiny\n2 2\n255\n255 0 0  0 255 0\n0 0 255  9 8 7\n")
+    monkeypatch.setenv("RTW_ASSET_DIR", str(tmp_path))
+    s2 = abi.parse_scene(abi.build_scene(2, 32, 32))
+    words = np.frombuffer(s2["texdata"], "<u4")
+    img = [t for t in s2["textures"] if t.type == abi.TEX_IMAGE][0].data
+    assert list(words[img:img + 2]) == [2, 2]
+    # texture row 0 is the file's last row
+    assert list(words[img + 2:img + 6]) == [0xff000000 | (255 << 16), 0xff000000 | 9 | (8 << 8) | (7 << 16), 0xff000000 | 255, 0xff000000 | (255 << 8)]
 
 
 def test_host_builder_reproduces_fixture_blobs():
