@@ -201,6 +201,23 @@ def main():
                                         for i in range(4)},
                          "render_device_seconds_rank0": round(r_s, 4)},
         }
+        if world == 1:
+            # what a plain device-to-device copy of 2 GiB reaches on this very GPU, measured after the timed region:
+            # the practical ceiling for a read+write stream, to read the fractions of the 8 TB/s spec peak against
+            try:
+                src = torch.empty(1 << 29, dtype=torch.float32, device=dev)
+                dst = torch.empty_like(src)
+                dst.copy_(src); torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    dst.copy_(src)
+                e1.record(); torch.cuda.synchronize()
+                line["roofline"]["device_copy_GBps"] = round(5 * 2 * src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+                del src, dst
+            except Exception as ex:  # measurement aid only
+                line["roofline"]["device_copy_GBps"] = None
+                print(f"[bench] device copy probe failed: {ex}", file=sys.stderr)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(blob, abi)
         print(json.dumps(line), flush=True)

@@ -14,6 +14,9 @@ CONFIGS = [
     ("C4 Cornell+fog 1920x1080 2048spp depth 50", 3, 1920, 1080, 2048, 50),
     ("Target Cornell 1920x1080 4096spp depth 50", 0, 1920, 1080, 4096, 50),
     ("C5-tile Cornell 7680x4320 tile rows 0-539 (1/8), 256spp depth 50", 0, 7680, 4320, 256, 50),
+    # SURVEY 8f rank 1 scenes (not BASELINE configurations): textures, 520 / 3410 primitives
+    ("F1 scene 2 (spheres + light, noise/image textures) 1920x1080 256spp depth 50", 2, 1920, 1080, 256, 50),
+    ("F2 scene 4 (The Next Week final) 1920x1080 128spp depth 50", 4, 1920, 1080, 128, 50),
 ]
 r = abi.Renderer(0)
 for name, scene, w, h, spp, depth in CONFIGS:
