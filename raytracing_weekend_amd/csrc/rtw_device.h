@@ -617,6 +617,29 @@ RTW_DEV v3 recip3(v3 d) { return V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 // Candidate order (observable only through volume RNG draws and exact ties in t): volume
 // primitives in index order, then everything else with ties resolved to the lowest index.
 // tm: this thread's column of the LDS traversal stack and the block's LDS node cache (trav_mem).
+// The volume primitives' share of a traversal: tested first, in index order, each against the interval the earlier
+// ones left (their intersection programs draw random numbers: geometry/volumeBox.cu:79, volumeSphere.cu:93).
+// Surfaces then only win with a strictly smaller t, so a kernel that holds the generator can run this pass on its
+// own and combine it with a surface-only closest hit found elsewhere: min over both, the volume keeping ties.
+template <class RNG, bool ANY_HIT>
+RTW_DEV bool volume_pass(const DScene& sc, v3 o, v3 d, float tmin, float ray_time, float gather_time, RNG& g, float& best_t, int& best_prim) {
+    bool hit = false;
+    for (int k = 0; k < sc.n_vol; k++) {
+        int pi = load_i32(sc.order + k);
+        const rtw_prim pr = load_prim(sc, pi);
+        v3 po, pd, mt;
+        object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+        float t;
+        if (prim_test(pr, po, pd, recip3(pd), tmin, best_t, gather_time, g, t)) {
+            best_t = t;
+            best_prim = pi;
+            hit = true;
+            if (ANY_HIT) return true;
+        }
+    }
+    return hit;
+}
+
 template <class RNG, bool ANY_HIT, bool SKIP_VOLUMES>
 RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, float ray_time, float gather_time, RNG& g,
                       const TravMem& tm, float& best_t, int& best_prim) {
@@ -625,19 +648,8 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
     // volumes first, in index order
     bool best_is_vol = false;
     if (!SKIP_VOLUMES) {
-        for (int k = 0; k < sc.n_vol; k++) {
-            int pi = load_i32(sc.order + k);
-            const rtw_prim pr = load_prim(sc, pi);
-            v3 po, pd, mt;
-            object_ray(sc, pr, o, d, ray_time, po, pd, mt);
-            float t;
-            if (prim_test(pr, po, pd, recip3(pd), tmin, best_t, gather_time, g, t)) {
-                best_t = t;
-                best_prim = pi;
-                best_is_vol = true;
-                if (ANY_HIT) return;
-            }
-        }
+        best_is_vol = volume_pass<RNG, ANY_HIT>(sc, o, d, tmin, ray_time, gather_time, g, best_t, best_prim);
+        if (ANY_HIT && best_is_vol) return;
     }
     // The closest hit is the minimum over (t, primitive index) of the non-volume candidates, which is
     // what the oracle's index-order scan with a strict '<' yields; written this way the candidates

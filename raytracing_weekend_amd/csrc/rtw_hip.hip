@@ -161,16 +161,18 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_POOL_PATHS  paths in flight over all lanes (default 2^28: 55 GiB of state, sized for 288 GB of HBM)
 //   RTW_LANES       stream lanes that overlap consecutive batches (default 2; 1..4)
 //   RTW_GRID_MULT   persistent workgroups per CU (default 8 with one lane, 4 with two)
-//   RTW_TAIL_START  first bounce handled by the fused multi-bounce tail launches (default 6)
-//   RTW_FUSED=1     every bounce through the fused k_bounce (what scenes with volumes always do)
+//   RTW_TAIL_START  first bounce handled by the fused multi-bounce tail launches (default 6; 20 for tree scenes)
+//   RTW_FUSED=1     every bounce through the fused k_bounce
+//   RTW_SPLIT_MEDIA=0  scenes with media: every bounce through k_bounce (default: split pipeline, volumes tested in the shading kernels)
 //   RTW_BRUTE_MAX   largest primitive count walked with the scalar-cache brute lists (default 24; 0 forces the BVH)
 //   RTW_LDS_KB      dynamic LDS per workgroup for traversal stacks + staged tree nodes (default 16)
 struct Tuning {
     size_t pool_paths = (size_t)1 << 28;
     int lanes = 2;
     int grid_mult = 0;   // 0 = automatic
-    int tail_start = 6;
+    int tail_start = 0;  // 0 = automatic: 6 for the brute-list scenes, 20 for tree scenes
     bool fused = false;
+    bool split_media = true;  // RTW_SPLIT_MEDIA=0: scenes with media keep every bounce in k_bounce
     int brute_max = kBruteMaxPrims;
     size_t lds_kb = 16;
 };
@@ -188,6 +190,7 @@ Tuning read_tuning() {
     if (geti("RTW_GRID_MULT", v)) t.grid_mult = (int)std::max<long long>(1, v);
     if (geti("RTW_TAIL_START", v)) t.tail_start = (int)std::max<long long>(1, v);
     if (geti("RTW_FUSED", v)) t.fused = v == 1;
+    if (geti("RTW_SPLIT_MEDIA", v)) t.split_media = v != 0;
     if (geti("RTW_BRUTE_MAX", v)) t.brute_max = (int)v;
     if (geti("RTW_LDS_KB", v)) t.lds_kb = (size_t)std::max<long long>(0, v);
     return t;
@@ -471,7 +474,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.recs = (const BruteRec*)(d + o_recs);
     sc.texs = (const rtw_texture*)(d + o_texs);
     sc.texdata = (const uint32_t*)(d + o_texdata);
-    sc.has_tex = has_tex;
+    sc.has_tex = (has_tex || n_vol > 0) ? 1 : 0;  // selects the kernel instantiations that contain the texture and media code
     sc.n_groups = (int)groups.size();
     sc.n_generic = n_generic;
     sc.n_prims = (int)h.n_prims;
@@ -560,8 +563,10 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     struct Step { int kind, depth, n_iter; };
     std::vector<Step> sched;
     {
-        const int tail_start = tune.tail_start;
-        const bool split = c->sc.n_vol == 0 && !tune.fused;
+        // the fused tail kernel walks the tree one lane per path (lane utilisation 0.2): tree scenes stay in the split
+        // pipeline longer (scene 4: +18 % at 24 vs 6; scenes 1, 2: flat)
+        const int tail_start = tune.tail_start > 0 ? tune.tail_start : (c->sc.use_bvh ? 20 : 6);
+        const bool split = !tune.fused && (c->sc.n_vol == 0 || tune.split_media);
         int d = 0, grp = 2, rep = 0;
         while (d < P->max_depth) {
             if (d < tail_start) {

@@ -166,6 +166,7 @@ struct Nee {
 
 // Closest-hit / miss program up to and including the light sample (shaders/closehit.cu:45-94,
 // miss/miss.cu:8-30, material/*.cu, pdf/mixturePdf.cu:25-38, pdf/rectPdf.cu:124-193).
+// TEX: the instantiation for scenes with non-constant textures or media (the cold features)
 template <int KIND, bool TEX>
 RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 dir, const float gather_time, const float t, const int prim,
                     v3& so, v3& sd, v3& att, v3& radiance, Nee& nee) {
@@ -537,15 +538,24 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             // camera rays of a chunk are neighbours: in a 16:9 Cornell frame 4 waves in 10 look past the box entirely,
             // and a wave-uniform test against the scene bounds spares them the walk over the candidate lists
             th = 1.e27f; prim = -1;
-            if (__ballot(may_hit_scene(A.sc, p.o, p.d)) != 0ull)
-                traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
+            if (__ballot(may_hit_scene(A.sc, p.o, p.d)) != 0ull) {
+                if (TEX && A.sc.n_vol > 0) traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, g, tm, th, prim);
+                else traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
+            }
             v3 so, sd, att, radiance;
             Nee nee;
             const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
             n_seg++;
             if (nee.has) {
-                p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T);
                 n_shadow++;
+                bool fogged = false;
+                if (TEX && A.sc.n_vol > 0) {  // the probe's volume share, in draw order (see k_shade)
+                    float tv = nee.tmax;
+                    int pv = -1;
+                    fogged = volume_pass<Rng<KIND>, true>(A.sc, so, nee.dir, nee.tmin, 0.0f, gt, g, tv, pv);
+                }
+                if (fogged) nee.has = false;
+                else { p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T); }
             }
             const bool alive = shade_b<KIND>(0u, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L);
             p.a = g.a; p.b = g.b;
@@ -566,7 +576,8 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
 }
 
 // ------------------------------------------------------------------ k_trace
-// Only scenes without volume primitives reach this kernel, so no intersection program draws random numbers.
+// Surfaces only: no intersection program that draws random numbers runs here. In scenes with media the volume
+// primitives are tested by the shading kernels, which hold the generator (volume_pass in rtw_device.h).
 // DUAL = 1: small static scenes, both rays share one walk over the scalar-cache candidate lists (64 VGPRs, 8 waves);
 // DUAL = 0: BVH / moving-sphere scenes, one traversal per ray (the 64-byte node records want the larger budget).
 #ifndef RTW_TRACE_BVH_WAVES
@@ -789,15 +800,30 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
                 Rng<KIND> g;
                 rng_from_path<KIND>(g, A.seed, p);
                 const float gt = gather_time_of(A, p.gk);
-                const int prim = (int)(h.y & 0x3fffffffu) - 1;
+                int prim = (int)(h.y & 0x3fffffffu) - 1;
+                float th = __uint_as_float(h.x);
+                if (TEX && A.sc.n_vol > 0) {
+                    // scenes with media: k_trace found the closest surface; the volumes are tested here, where the
+                    // generator lives, before this segment's closest-hit draws - the reference's order
+                    float tv = 1.e27f;
+                    int pv = -1;
+                    if (volume_pass<Rng<KIND>, false>(A.sc, p.o, p.d, 1e-6f, p.ray_time, gt, g, tv, pv) && !(prim >= 0 && th < tv)) { th = tv; prim = pv; }
+                }
                 v3 so, sd, att, radiance;
                 Nee nee;
-                const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, __uint_as_float(h.x), prim, so, sd, att, radiance, nee);
+                const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
                 n_seg++;
                 p.ltmax = -1.0f;
                 if (nee.has) {
-                    p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T);
                     n_shadow++;
+                    bool fogged = false;
+                    if (TEX && A.sc.n_vol > 0) {  // the probe's volume share (any hit), right after the light-sample draws
+                        float tv = nee.tmax;
+                        int pv = -1;
+                        fogged = volume_pass<Rng<KIND>, true>(A.sc, so, nee.dir, nee.tmin, 0.0f, gt, g, tv, pv);
+                    }
+                    if (fogged) nee.has = false;
+                    else { p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T); }
                 }
                 const bool alive = shade_b<KIND>(A.depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L);
                 if (ev == EV_HIT) p.o = so;  // a queued probe starts at the hit point even when the path stops here
@@ -843,10 +869,11 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
             Rng<KIND> g;
             rng_from_path<KIND>(g, A.seed, p);
             const float gt = gather_time_of(A, p.gk);
-            if (p.ltmax >= 0.0f) {  // a probe queued by k_shade: resolve it here
+            if (p.ltmax >= 0.0f) {  // a probe queued by k_first / k_shade: its volume share was decided there, with the
+                                    // generator in the reference's draw order; what is left is the surfaces
                 float st;
                 int sprim;
-                traverse<Rng<KIND>, true, false>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, g, tm, st, sprim);
+                traverse<Rng<KIND>, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, g, tm, st, sprim);
                 if (sprim < 0) p.L = vadd(p.L, p.c);
                 p.ltmax = -1.0f;
             }
