@@ -133,34 +133,39 @@ inline void build(std::vector<Item>& items, int lo, int hi, int node_idx, int de
         out.nodes[node_idx].count = static_cast<uint32_t>(n);
         return;
     }
-    // binned SAH over the widest centroid axis
+    // binned SAH (16 bins), best split over all three centroid axes
     int axis = 0;
     float ext = -1.f;
     for (int a = 0; a < 3; a++) { float e = cb.mx[a] - cb.mn[a]; if (e > ext) { ext = e; axis = a; } }
     int mid = (lo + hi) / 2;
     if (ext > 0.f) {
         const int NB = 16;
-        Box bb[NB]; int bc[NB] = {0};
-        float k = NB * (1.f - 1e-6f) / ext;
-        for (int i = lo; i < hi; i++) {
-            int bi = std::min(NB - 1, std::max(0, static_cast<int>((items[i].c[axis] - cb.mn[axis]) * k)));
-            bb[bi].add(items[i].b); bc[bi]++;
+        float best = FLT_MAX; int best_split = -1, best_axis = axis; float best_k = 0.f;
+        for (int ax = 0; ax < 3; ax++) {
+            const float e = cb.mx[ax] - cb.mn[ax];
+            if (!(e > 0.f)) continue;
+            Box bb[NB]; int bc[NB] = {0};
+            const float k = NB * (1.f - 1e-6f) / e;
+            for (int i = lo; i < hi; i++) {
+                int bi = std::min(NB - 1, std::max(0, static_cast<int>((items[i].c[ax] - cb.mn[ax]) * k)));
+                bb[bi].add(items[i].b); bc[bi]++;
+            }
+            Box accl[NB]; int cntl[NB];
+            Box run; int rc = 0;
+            for (int i = 0; i < NB; i++) { if (bc[i]) run.add(bb[i]); rc += bc[i]; accl[i] = run; cntl[i] = rc; }
+            Box runr; int rcr = 0;
+            for (int i = NB - 1; i >= 1; i--) {
+                if (bc[i]) runr.add(bb[i]);
+                rcr += bc[i];
+                if (cntl[i - 1] == 0 || rcr == 0) continue;
+                float cost = accl[i - 1].area() * cntl[i - 1] + runr.area() * rcr;
+                if (cost < best) { best = cost; best_split = i; best_axis = ax; best_k = k; }
+            }
         }
-        float best = FLT_MAX; int best_split = -1;
-        Box accl[NB]; int cntl[NB];
-        Box run; int rc = 0;
-        for (int i = 0; i < NB; i++) { if (bc[i]) run.add(bb[i]); rc += bc[i]; accl[i] = run; cntl[i] = rc; }
-        Box runr; int rcr = 0;
-        for (int i = NB - 1; i >= 1; i--) {
-            if (bc[i]) runr.add(bb[i]);
-            rcr += bc[i];
-            if (cntl[i - 1] == 0 || rcr == 0) continue;
-            float cost = accl[i - 1].area() * cntl[i - 1] + runr.area() * rcr;
-            if (cost < best) { best = cost; best_split = i; }
-        }
+        axis = best_axis;
         if (best_split > 0) {
             auto it = std::partition(items.begin() + lo, items.begin() + hi, [&](const Item& it2) {
-                int bi = std::min(NB - 1, std::max(0, static_cast<int>((it2.c[axis] - cb.mn[axis]) * k)));
+                int bi = std::min(NB - 1, std::max(0, static_cast<int>((it2.c[axis] - cb.mn[axis]) * best_k)));
                 return bi < best_split;
             });
             mid = static_cast<int>(it - items.begin());
