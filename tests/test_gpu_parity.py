@@ -197,6 +197,33 @@ def test_textured_scene_through_the_fused_path(gpu):
     check(img, ref, st, st_ref)
 
 
+def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
+    """Lanes, pool size, tail start, fused vs split (with and without media), LDS budget, grid size: tuning knobs move
+    work between kernels and streams, never a bit of the image or a count."""
+    cases = [(abi.build_scene(0, 96, 64), 96, 64, 12, 30), (abi.build_scene(3, 64, 64), 64, 64, 10, 30),
+             (oracle.random_scene(18, 80, 60, n_prims=70, volumes=True, motion=True, n_lights=2), 80, 60, 6, 30),
+             (oracle.textured_cornell(64, 48, extra=30), 64, 48, 6, 20)]
+    knobs = [{}, {"RTW_LANES": "1"}, {"RTW_LANES": "3", "RTW_POOL_PATHS": "20000"}, {"RTW_FUSED": "1"}, {"RTW_SPLIT_MEDIA": "0"},
+             {"RTW_TAIL_START": "2"}, {"RTW_TAIL_START": "40", "RTW_GRID_MULT": "1"}, {"RTW_LDS_KB": "0"},
+             {"RTW_LDS_KB": "48", "RTW_BRUTE_MAX": "0"}, {"RTW_POOL_PATHS": "4096", "RTW_GRID_MULT": "3"}]
+    names = sorted({k for kn in knobs for k in kn})
+    for blob, w, h, spp, depth in cases:
+        ref = None
+        for kn in knobs:
+            for n in names:
+                monkeypatch.delenv(n, raising=False)
+            for n, v in kn.items():
+                monkeypatch.setenv(n, v)
+            gpu.upload_scene(blob)  # RTW_BRUTE_MAX / RTW_LDS_KB are read at upload, the rest per render
+            img, st = gpu.render(abi.make_params(w, h, spp, depth))
+            if ref is None:
+                ref = (img, st.segments, st.shadow_rays)
+            else:
+                assert np.array_equal(img, ref[0]) and (st.segments, st.shadow_rays) == ref[1:], kn
+    for n in names:
+        monkeypatch.delenv(n, raising=False)
+
+
 def test_edge_cases(gpu):
     blob = abi.build_scene(0, 8, 8)
     gpu.upload_scene(blob)
