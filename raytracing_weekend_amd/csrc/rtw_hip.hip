@@ -4,11 +4,12 @@
 // closest-hit/miss -> callables, one thread per pixel, one sample) is done here as a wavefront loop over
 // batches of S samples per pixel (P = pixels*S paths in flight, sized for HBM, not for cache):
 //
-//   k_first                     primary rays + their closest hit
-//   repeat for the wide bounces (scenes without volumes):
-//     k_shade                   material scatter, light sample (shadow probe queued), roulette, compaction
-//     k_trace                   radiance ray + queued shadow probe of every surviving path (high occupancy)
+//   k_first                     primary rays, their closest hit and closest-hit program (light sample queued)
+//   repeat for the wide bounces (1..5; 1..19 in tree scenes):
+//     k_trace / k_trace_bvh     radiance ray + queued shadow probe of every surviving path, surfaces only
+//     k_shade                   (volume pass,) material scatter, light sample (shadow probe queued), roulette, compaction
 //   k_bounce x few              thin tail: several fused bounces per launch, in registers
+//   two batches are in flight on two streams ("lanes"); the resolves stay ordered on the caller's stream
 //   k_resolve                   sums the S sample slots of each pixel in sample order (deterministic)
 //   k_finish (once)             mean radiance -> float4 framebuffer tile
 //

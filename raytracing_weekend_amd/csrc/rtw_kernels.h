@@ -1,14 +1,14 @@
 // rtw_kernels.h — the wavefront kernels (gfx950). See rtw_hip.hip for the launch schedule.
 //
-//   k_first   generate primary rays (raygen.cu:123-147, camera.cu:11-19) and trace them
-//   k_shade   closest-hit / miss programs for one bounce of every live path: material scatter, light
-//             sampling (the shadow ray is QUEUED in the path state, not traced), Russian roulette,
-//             wave64 ballot/popcount compaction of the survivors into the other ping-pong buffer
-//   k_trace   lean, high-occupancy intersection pass over the compacted paths: the radiance ray's
-//             closest hit and the queued shadow ray's any-hit, both from the same origin
-//   k_bounce  fused trace+shade(+inline shadow probe) for several bounces in registers: the thin tail
-//             of a batch (latency-bound launches) and scenes whose intersection programs draw
-//             random numbers (volumes), where trace and shade cannot be separated
+//   k_first      generate primary rays (raygen.cu:123-147, camera.cu:11-19), trace and shade the primary segment
+//   k_shade      closest-hit / miss programs for one bounce of every live path: (media: the volume pass), material
+//                scatter, texture, light sampling (the shadow ray is QUEUED in the path state, not traced), Russian
+//                roulette, wave64 ballot/popcount compaction of the survivors into the workgroup's own output region
+//   k_trace<>    surfaces only, small scenes: the radiance ray's closest hit and the queued shadow ray's any-hit in one
+//                shared walk over the scalar-cache candidate lists (or one traverse<> each with moving spheres)
+//   k_trace_bvh  surfaces only, tree scenes: waves own streams of chunks, idle lanes refill, majority-vote stepping
+//   k_bounce     fused trace+shade(+inline shadow probe) for several bounces in registers: the thin tail of a batch
+//                (latency-bound launches); every bounce with RTW_FUSED=1 / RTW_SPLIT_MEDIA=0
 //   k_resolve / k_finish   deterministic per-pixel sum of the sample slots, mean radiance
 //
 // Path state: six 16-byte SoA planes per path (96 B), read and written with dwordx4 accesses that
@@ -46,7 +46,7 @@ struct KArgs {
     float4* lbuf;               // per path id: final radiance of the sample
     const uint32_t* cnt_in;     // live paths per region (input)
     uint32_t* cnt_out;          // live paths per region (output): region b is written by workgroup b alone
-    unsigned long long* stats;  // [0] segments, [1] shadow probes, [2 + kind] segments per kernel kind
+    unsigned long long* stats;  // kStatRows rows of 8: [0] segments, [1] shadow probes, [2 + kind] units per kernel kind
     uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, trace_first;
     uint32_t row_stride;        // >= 1: local row l of the shard is image row row0 + l*row_stride
     uint32_t divw_m, divw_s1, divw_s2;  // exact division by width (multiply-high + shifts)
