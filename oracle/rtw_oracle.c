@@ -251,9 +251,13 @@ static int scene_open(scene_t* s, const void* blob, size_t bytes) {
     s->texs = (const rtw_texture*)(b + h->off_textures);
     s->lights = (const rtw_light*)(b + h->off_lights);
     for (uint32_t i = 0; i < h->n_prims; i++) {
+        if (s->prims[i].type < RTW_PRIM_SPHERE || s->prims[i].type > RTW_PRIM_VOLUME_SPHERE) return RTW_ERR_BAD_SCENE;
         if (s->prims[i].xform < 0 || (uint32_t)s->prims[i].xform >= h->n_xforms) return RTW_ERR_BAD_SCENE;
         if (s->prims[i].material < 0 || (uint32_t)s->prims[i].material >= h->n_materials) return RTW_ERR_BAD_SCENE;
+        for (int k = 0; k < 12; k++) if (!isfinite(s->prims[i].p[k])) return RTW_ERR_BAD_SCENE;
     }
+    for (uint32_t i = 0; i < h->n_xforms; i++)
+        for (int k = 0; k < 12; k++) if (!isfinite(s->xforms[i].m[k]) || !isfinite(s->xforms[i].inv[k])) return RTW_ERR_BAD_SCENE;
     s->texdata = NULL;
     s->texdata_words = 0;
     if (h->off_texdata) {

@@ -292,7 +292,11 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (h.n_textures) memcpy(texs.data(), b + h.off_textures, h.n_textures * sizeof(rtw_texture));
     if (h.n_lights) memcpy(lights.data(), b + h.off_lights, h.n_lights * sizeof(rtw_light));
 
-    // texture data section and texture records (same rules as the oracle's scene_open)
+    for (const rtw_xform& x : xforms)
+        for (int k = 0; k < 12; k++) if (!std::isfinite(x.m[k]) || !std::isfinite(x.inv[k])) return fail(c, RTW_ERR_BAD_SCENE, "transform not finite");
+    for (const rtw_material& m : mats)
+        if (m.texture >= (int32_t)h.n_textures) return fail(c, RTW_ERR_BAD_SCENE, "material texture out of range");
+    // texture data section and texture records (the test-side checker applies the same rules)
     std::vector<uint32_t> texdata;
     if (h.off_texdata) {
         if ((h.off_texdata & 3u) || (size_t)h.off_texdata + (size_t)h.texdata_bytes > bytes) return fail(c, RTW_ERR_BAD_SCENE, "texture data section out of range");
@@ -324,6 +328,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         if (p.type < RTW_PRIM_SPHERE || p.type > RTW_PRIM_VOLUME_SPHERE) return fail(c, RTW_ERR_BAD_SCENE, "unknown primitive type");
         if (p.xform < 0 || (uint32_t)p.xform >= h.n_xforms) return fail(c, RTW_ERR_BAD_SCENE, "primitive xform out of range");
         if (p.material < 0 || (uint32_t)p.material >= h.n_materials) return fail(c, RTW_ERR_BAD_SCENE, "primitive material out of range");
+        for (int k = 0; k < 12; k++) if (!std::isfinite(p.p[k])) return fail(c, RTW_ERR_BAD_SCENE, "primitive parameter not finite");
         if (p.type == RTW_PRIM_MOVING_SPHERE) has_motion = 1;
         const rtw_material& m = mats[p.material];
         HitRec s{};

@@ -259,3 +259,66 @@ def textured_cornell(w, h, extra=0):
         prims.append(pr)
     parts.update(prims=prims, materials=mats, textures=texs, texdata=bytes(texdata))
     return abi.assemble_scene(parts)
+
+
+def corrupted_scenes(w=24, h=16):
+    """(name, blob) pairs every loader must reject (RTW_ERR_BAD_SCENE) - the oracle and the HIP library alike."""
+    import ctypes as C
+    import numpy as np
+    from raytracing_weekend_amd import abi
+    base = dict(abi.parse_scene(textured_cornell(w, h)))
+    out = []
+
+    def variant(name, edit):
+        parts = {k: (list(v) if k not in ("header", "texdata") else v) for k, v in base.items()}
+        parts["prims"] = [abi.Prim.from_buffer_copy(bytes(p)) for p in parts["prims"]]
+        parts["materials"] = [abi.Material.from_buffer_copy(bytes(m)) for m in parts["materials"]]
+        parts["textures"] = [abi.Texture.from_buffer_copy(bytes(t)) for t in parts["textures"]]
+        parts["xforms"] = [abi.Xform.from_buffer_copy(bytes(x)) for x in parts["xforms"]]
+        edit(parts)
+        out.append((name, abi.assemble_scene(parts)))
+
+    def set_attr(table, i, field, value):
+        def edit(parts):
+            setattr(parts[table][i], field, value)
+        return edit
+
+    def set_p(i, k, value):
+        def edit(parts):
+            parts["prims"][i].p[k] = value
+        return edit
+    n_mat, n_tex = len(base["materials"]), len(base["textures"])
+    checker = [i for i, t in enumerate(base["textures"]) if t.type == abi.TEX_CHECKER][0]
+    image = [i for i, t in enumerate(base["textures"]) if t.type == abi.TEX_IMAGE][0]
+    variant("primitive type", set_attr("prims", 0, "type", 7))
+    variant("primitive type negative", set_attr("prims", 1, "type", -1))
+    variant("primitive xform", set_attr("prims", 2, "xform", 99))
+    variant("primitive material", set_attr("prims", 3, "material", n_mat))
+    variant("primitive material negative", set_attr("prims", 3, "material", -2))
+    variant("primitive parameter nan", set_p(4, 1, float("nan")))
+    variant("primitive parameter inf", set_p(5, 4, float("inf")))
+    variant("material texture", set_attr("materials", 0, "texture", n_tex))
+    variant("texture type", set_attr("textures", 0, "type", 5))
+    variant("checker child", set_attr("textures", checker, "odd", n_tex))
+    variant("checker child negative", set_attr("textures", checker, "even", -1))
+    variant("checker nested", set_attr("textures", checker, "odd", checker))
+    variant("image beyond the data section", set_attr("textures", image, "data", len(base["texdata"]) // 4 - 3))
+
+    def nan_xform(parts):
+        parts["xforms"][1].inv[3] = float("nan")
+    variant("transform nan", nan_xform)
+
+    def huge_image(parts):
+        words = np.frombuffer(parts["texdata"], "<u4").copy()
+        words[parts["textures"][image].data] = 30000
+        parts["texdata"] = words.tobytes()
+    variant("image size larger than its texels", huge_image)
+    blob = abi.assemble_scene(base)
+    hdr = abi.SceneHeader.from_buffer_copy(blob[:C.sizeof(abi.SceneHeader)])
+    for name, field, value in (("prim table offset", "off_prims", len(blob)), ("texture data offset", "off_texdata", len(blob) + 4),
+                               ("texture data misaligned", "off_texdata", hdr.off_texdata + 2), ("no transforms", "n_xforms", 0),
+                               ("light table", "n_lights", 1 << 20)):
+        h2 = abi.SceneHeader.from_buffer_copy(bytes(hdr))
+        setattr(h2, field, value)
+        out.append((name, bytes(h2) + blob[C.sizeof(abi.SceneHeader):]))
+    return out

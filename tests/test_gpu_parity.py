@@ -275,6 +275,25 @@ def test_error_behaviour():
     assert lib.rtw_destroy(ctx) == 0
 
 
+def test_corrupted_scenes_are_rejected():
+    """Out-of-range indices, non-finite parameters, broken texture tables and offsets: RTW_ERR_BAD_SCENE with a message,
+    the context stays usable (the same matrix the oracle rejects in the CPU suite)."""
+    lib = abi.load_hip()
+    ctx = C.c_void_p()
+    dev = (C.c_int * 1)(0)
+    assert lib.rtw_create(C.byref(ctx), 1, dev) == 0
+    for name, blob in oracle.corrupted_scenes():
+        assert lib.rtw_upload_scene(ctx, blob, len(blob)) == -2, name
+        assert len(lib.rtw_last_error(ctx)) > 0
+    ok = oracle.textured_cornell(24, 16)
+    assert lib.rtw_upload_scene(ctx, ok, len(ok)) == 0
+    out = np.zeros((16, 24, 4), np.float32)
+    st = abi.Stats()
+    p = abi.make_params(24, 16, 1, 2)
+    assert lib.rtw_render(ctx, C.byref(p), out.ctypes.data, C.byref(st)) == 0 and np.isfinite(out).all()
+    assert lib.rtw_destroy(ctx) == 0
+
+
 @pytest.mark.parametrize("scene", [0, 1])
 def test_traversal_matches_brute_force(gpu, scene):
     """Scalar-cache brute lists (scene 0) and the BVH (scene 1) against the oracle's index-order scan,

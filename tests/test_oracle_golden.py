@@ -213,3 +213,14 @@ def test_textured_scene_on_the_oracle():
     texs[noise] = abi.Texture(type=9)
     broken = abi.assemble_scene(parts)
     assert lib.rtwo_render(broken, len(broken), C.byref(p), out.ctypes.data, C.byref(st2), 1) == -2
+
+
+def test_corrupted_scenes_are_rejected_by_the_oracle():
+    lib = oracle.load()
+    p = abi.make_params(24, 16, 1, 2)
+    out = np.zeros((16, 24, 4), np.float32)
+    st = abi.Stats()
+    ok = oracle.textured_cornell(24, 16)
+    assert lib.rtwo_render(ok, len(ok), C.byref(p), out.ctypes.data, C.byref(st), 1) == 0
+    for name, blob in oracle.corrupted_scenes():
+        assert lib.rtwo_render(blob, len(blob), C.byref(p), out.ctypes.data, C.byref(st), 1) == -2, name
