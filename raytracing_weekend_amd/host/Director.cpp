@@ -7,6 +7,7 @@
 #include "Director.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -130,5 +131,71 @@ bool Director::writePFM(const std::string& path) const {
         }
         f.write(reinterpret_cast<const char*>(row.data()), static_cast<std::streamsize>(row.size() * sizeof(float)));
     }
+    return static_cast<bool>(f);
+}
+
+// PNG without a compression library: zlib stream of stored deflate blocks (the reference vendors stb_image_write.h for
+// this and never calls it, main.cpp:9). CRC-32 and Adler-32 as in RFC 1950 / the PNG specification.
+bool Director::writePNG(const std::string& path) const {
+    std::ofstream f(path, std::ios::binary);
+    if (!f) return false;
+    uint32_t crcTable[256];
+    for (uint32_t n = 0; n < 256; n++) {
+        uint32_t c = n;
+        for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+        crcTable[n] = c;
+    }
+    auto be32 = [](std::vector<unsigned char>& v, uint32_t x) {
+        v.push_back(static_cast<unsigned char>(x >> 24)); v.push_back(static_cast<unsigned char>(x >> 16));
+        v.push_back(static_cast<unsigned char>(x >> 8)); v.push_back(static_cast<unsigned char>(x));
+    };
+    auto chunk = [&](const char* type, const std::vector<unsigned char>& data) {
+        std::vector<unsigned char> c;
+        be32(c, static_cast<uint32_t>(data.size()));
+        c.insert(c.end(), type, type + 4);
+        c.insert(c.end(), data.begin(), data.end());
+        uint32_t crc = 0xffffffffu;
+        for (size_t i = 4; i < c.size(); i++) crc = crcTable[(crc ^ c[i]) & 0xffu] ^ (crc >> 8);
+        be32(c, crc ^ 0xffffffffu);
+        f.write(reinterpret_cast<const char*>(c.data()), static_cast<std::streamsize>(c.size()));
+    };
+    auto enc = [](float c) {
+        float g = std::sqrt(c);
+        g = g < 0.f ? 0.f : (g > 1.f ? 1.f : g);
+        if (!(g == g)) g = 0.f;
+        return static_cast<unsigned char>(static_cast<int>(255.99f * g));
+    };
+    const unsigned char sig[8] = {0x89, 'P', 'N', 'G', '\r', '\n', 0x1a, '\n'};
+    f.write(reinterpret_cast<const char*>(sig), 8);
+    std::vector<unsigned char> ihdr;
+    be32(ihdr, static_cast<uint32_t>(m_Nx)); be32(ihdr, static_cast<uint32_t>(m_Ny));
+    ihdr.push_back(8); ihdr.push_back(2); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);  // 8 bit, RGB, no interlace
+    chunk("IHDR", ihdr);
+    // raw scanlines (filter byte 0 + RGB), top row first
+    std::vector<unsigned char> raw;
+    raw.reserve((static_cast<size_t>(m_Nx) * 3 + 1) * m_Ny);
+    for (int j = m_Ny - 1; j >= 0; j--) {
+        raw.push_back(0);
+        for (int i = 0; i < m_Nx; i++) {
+            const float* px = &m_hostBuffer[(static_cast<size_t>(m_Nx) * j + i) * 4];
+            raw.push_back(enc(px[0])); raw.push_back(enc(px[1])); raw.push_back(enc(px[2]));
+        }
+    }
+    std::vector<unsigned char> z;
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0;
+    for (size_t pos = 0; pos < raw.size() || pos == 0;) {
+        const size_t n = std::min<size_t>(65535, raw.size() - pos);
+        z.push_back(pos + n >= raw.size() ? 1 : 0);  // BFINAL, BTYPE = 00 (stored)
+        z.push_back(static_cast<unsigned char>(n)); z.push_back(static_cast<unsigned char>(n >> 8));
+        z.push_back(static_cast<unsigned char>(~n)); z.push_back(static_cast<unsigned char>((~n) >> 8));
+        for (size_t i = 0; i < n; i++) { a = (a + raw[pos + i]) % 65521u; b = (b + a) % 65521u; }
+        z.insert(z.end(), raw.begin() + static_cast<std::ptrdiff_t>(pos), raw.begin() + static_cast<std::ptrdiff_t>(pos + n));
+        pos += n;
+        if (n == 0) break;
+    }
+    be32(z, (b << 16) | a);
+    chunk("IDAT", z);
+    chunk("IEND", {});
     return static_cast<bool>(f);
 }

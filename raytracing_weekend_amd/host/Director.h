@@ -23,6 +23,7 @@ public:
     // additions: an 8K frame is ~400 MB as ASCII P3; P6 is 100 MB, PFM keeps the linear floats
     bool writeBinaryPPM(const std::string& path) const;  // P6, same sqrt + 255.99 quantisation as printPPM
     bool writePFM(const std::string& path) const;        // "PF", little-endian, linear radiance, rows bottom-up
+    bool writePNG(const std::string& path) const;        // 8-bit RGB, same quantisation; stored (uncompressed) deflate blocks
 
     // additions over the reference (its depth is hard-wired to 20 at Director.cpp:42, its RNG to tea+lcg)
     void setMaxDepth(int depth) { m_maxRayDepth = depth; }

@@ -1,7 +1,7 @@
 // main.cpp — command-line front end, same flow and flags as the reference (RestOfLife/main.cpp:29-165):
 //   -s scene  -ns samples  -dx width  -dy height  -h  -v  -g
 // plus what the benchmark configurations need and the reference hard-wires:
-//   -d depth (reference: 20, Director.cpp:42)   -seed N   -rng philox|lcg   -gpu id   -o file.ppm|file.pfm
+//   -d depth (reference: 20, Director.cpp:42)   -seed N   -rng philox|lcg   -gpu id   -o file.ppm|file.png|file.pfm
 // The reference's resolution / sample clamps (main.cpp:21-27) are widened so that 200x200 and
 // 7680x4320 are reachable, and its scene range bug (only scene 4 selectable, main.cpp:69) is not kept.
 #include <chrono>
@@ -58,7 +58,7 @@ int main(int argc, char* argv[]) {
     -seed N        RNG seed
     -rng K         philox (default) or lcg (the reference's tea+lcg generator)
     -gpu N         Device ordinal
-    -o FILE        Write FILE instead of ASCII P3 on stdout: *.ppm = binary P6, *.pfm = linear float PFM
+    -o FILE        Write FILE instead of ASCII P3 on stdout: *.ppm = binary P6, *.png = 8-bit PNG, *.pfm = linear float PFM
 
     -h             This help message.
     -v             Verbose output.
@@ -110,8 +110,9 @@ int main(int argc, char* argv[]) {
     if (outPath.empty()) {
         director.printPPM();
     } else {
-        const bool pfm = outPath.size() > 4 && outPath.compare(outPath.size() - 4, 4, ".pfm") == 0;
-        if (!(pfm ? director.writePFM(outPath) : director.writeBinaryPPM(outPath))) {
+        auto ends = [&](const char* ext) { return outPath.size() > 4 && outPath.compare(outPath.size() - 4, 4, ext) == 0; };
+        const bool ok = ends(".pfm") ? director.writePFM(outPath) : ends(".png") ? director.writePNG(outPath) : director.writeBinaryPPM(outPath);
+        if (!ok) {
             std::cerr << "ERROR: cannot write " << outPath << std::endl;
             director.destroy();
             return EXIT_FAILURE;

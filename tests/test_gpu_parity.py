@@ -428,6 +428,8 @@ def test_cli_director_outputs(tmp_path):
     blob = abi.build_scene(0, w, h)
     ref, _ = oracle.render(blob, abi.make_params(w, h, spp, depth), threads=8)
     assert np.array_equal(img, ref[..., :3])
+    png = str(tmp_path / "o.png")
+    subprocess.run(args + ["-o", png], check=True, timeout=300)
     rawp = open(ppm, "rb").read()
     headp = f"P6\n{w} {h}\n255\n".encode()
     assert rawp.startswith(headp)
@@ -435,5 +437,24 @@ def test_cli_director_outputs(tmp_path):
     assert p3[0] == b"P3" and [int(x) for x in p3[1:4]] == [w, h, 255]
     px3 = np.array([int(x) for x in p3[4:]], dtype=np.uint8)
     assert np.array_equal(px6, px3)
+    # the PNG carries the same pixels: zlib-decode the IDAT chunks, strip the filter bytes
+    import struct
+    import zlib
+    d = open(png, "rb").read()
+    assert d[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, seen = 8, b"", []
+    while pos < len(d):
+        n, typ = struct.unpack(">I4s", d[pos:pos + 8])
+        body = d[pos + 8:pos + 8 + n]
+        assert struct.unpack(">I", d[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(typ + body) & 0xffffffff
+        seen.append(typ)
+        if typ == b"IHDR":
+            assert struct.unpack(">IIBBBBB", body) == (w, h, 8, 2, 0, 0, 0)
+        if typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    assert seen[0] == b"IHDR" and seen[-1] == b"IEND"
+    rows = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 3 * w)
+    assert np.all(rows[:, 0] == 0) and np.array_equal(rows[:, 1:].reshape(-1), px6)
     g = np.clip(np.sqrt(ref[::-1, :, :3].astype(np.float32)), np.float32(0), np.float32(1))  # image files run top-down
     assert np.array_equal(px6.reshape(h, w, 3), (np.float32(255.99) * g).astype(np.int32).astype(np.uint8))
