@@ -341,7 +341,8 @@ struct DScene {
     const uint32_t* __restrict__ texdata;    // noise tables, image texels (rtw.h rtw_texture)
     int32_t n_prims, n_vol, n_tree, n_lights, sky_light, use_bvh, has_motion, n_groups;
     int32_t n_generic;                       // order[n_vol .. n_vol+n_generic): moving spheres, tested through the generic path
-    int32_t n_lds_nodes, stack_depth, has_tex;  // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks
+    int32_t n_lds_nodes, stack_depth, has_tex, noise_lds_data;  // noise_lds_data: word offset of the noise tables staged in LDS, or -1
+    int32_t pad3;  // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks
     float bmin[3], bmax[3];                  // generous world bounds of everything (k_first's wave-uniform miss test)
     rtw_camera cam;
     rtw_pdf pdf;
@@ -878,11 +879,15 @@ RTW_DEV float perlin_noise(const uint32_t* __restrict__ tab, v3 p) {  // noiseTe
     const float uu = (u * u) * (3.0f - 2.0f * u);
     const float vv = (v * v) * (3.0f - 2.0f * v);
     const float ww = (w * w) * (3.0f - 2.0f * w);
+    // the six permutation entries the eight corners share (noiseTexture.cu:48-50 reads each of them four times)
+    const int x0 = px[i & 255], x1 = px[(i + 1) & 255];
+    const int y0 = py[j & 255], y1 = py[(j + 1) & 255];
+    const int z0 = pz[k & 255], z1 = pz[(k + 1) & 255];
     float accum = 0.0f;
-#pragma unroll 1
-    for (int c8 = 0; c8 < 8; c8++) {
+#pragma unroll
+    for (int c8 = 0; c8 < 8; c8++) {  // di, dj, dk nested in this order, as the reference accumulates
         const int di = c8 >> 2, dj = (c8 >> 1) & 1, dk = c8 & 1;
-        const int idx = (px[(i + di) & 255] ^ py[(j + dj) & 255] ^ pz[(k + dk) & 255]) & 255;
+        const int idx = ((di ? x1 : x0) ^ (dj ? y1 : y0) ^ (dk ? z1 : z0)) & 255;
         const v3 c = V(ranvec[3 * idx], ranvec[3 * idx + 1], ranvec[3 * idx + 2]);
         const v3 wv = V(u - (float)di, v - (float)dj, w - (float)dk);
         const float wi = di ? uu : 1.0f - uu, wj = dj ? vv : 1.0f - vv, wk = dk ? ww : 1.0f - ww;
@@ -926,7 +931,9 @@ RTW_DEV v3 image_fetch(const uint32_t* __restrict__ img, float u, float v) {  //
     return V(rgb[0], rgb[1], rgb[2]);
 }
 // texture/checkeredTexture.cu:8-19, noiseTexture.cu:69-78, imageTexture.cu, constantTexture.cu, nullTexture.cu
-RTW_DEV v3 texture_eval(const DScene& sc, const HitRec& h, int prim, v3 o, v3 d, float t, float ray_time, v3 p, v3 normal) {
+// noise_lds: the workgroup's LDS copy of the tables of the noise texture at sc.noise_lds_data (or nullptr): a Perlin
+// turbulence value is 7 x (6 + 24) table lookups at data-dependent addresses
+RTW_DEV v3 texture_eval(const DScene& sc, const HitRec& h, int prim, v3 o, v3 d, float t, float ray_time, v3 p, v3 normal, const uint32_t* noise_lds) {
     rtw_texture tx = sc.texs[h.tex_dyn];
     if (tx.type == RTW_TEX_CHECKER) {
         const float sines = (sin_spec(10.0f * p.x) * sin_spec(10.0f - p.y)) * sin_spec(10.0f * p.z);
@@ -934,8 +941,9 @@ RTW_DEV v3 texture_eval(const DScene& sc, const HitRec& h, int prim, v3 o, v3 d,
     }
     if (tx.type == RTW_TEX_CONSTANT) return V(tx.color[0], tx.color[1], tx.color[2]);
     if (tx.type == RTW_TEX_NOISE) {
-        const uint32_t* tab = sc.texdata + tx.data;
-        const float tb = perlin_turb(tab, vscale(p, tx.scale));
+        float tb;
+        if (noise_lds != nullptr && (int32_t)tx.data == sc.noise_lds_data) tb = perlin_turb(noise_lds, vscale(p, tx.scale));
+        else tb = perlin_turb(sc.texdata + tx.data, vscale(p, tx.scale));
         const float sn = sin_spec(tx.scale * p.z + 5.0f * tb);
         const float g = 0.5f * (1.0f + sn);
         return V(g, g, g);

@@ -480,6 +480,13 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.recs = (const BruteRec*)(d + o_recs);
     sc.texs = (const rtw_texture*)(d + o_texs);
     sc.texdata = (const uint32_t*)(d + o_texdata);
+    sc.noise_lds_data = -1;  // the first noise texture some primitive shows gets its tables staged in LDS
+    for (uint32_t i = 0; i < h.n_prims && sc.noise_lds_data < 0; i++) {
+        int ti = mats[prims[i].material].texture;
+        if (ti < 0) continue;
+        if (texs[ti].type == RTW_TEX_CHECKER) ti = texs[texs[ti].odd].type == RTW_TEX_NOISE ? texs[ti].odd : texs[ti].even;
+        if (texs[ti].type == RTW_TEX_NOISE) sc.noise_lds_data = (int32_t)texs[ti].data;
+    }
     sc.has_tex = (has_tex || n_vol > 0) ? 1 : 0;  // selects the kernel instantiations that contain the texture and media code
     sc.n_groups = (int)groups.size();
     sc.n_generic = n_generic;

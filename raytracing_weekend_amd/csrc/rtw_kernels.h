@@ -169,7 +169,7 @@ struct Nee {
 // TEX: the instantiation for scenes with non-constant textures or media (the cold features)
 template <int KIND, bool TEX>
 RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 dir, const float gather_time, const float t, const int prim,
-                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee) {
+                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee, const uint32_t* noise_lds) {
     radiance = V(0.f, 0.f, 0.f);
     att = V(0.f, 0.f, 0.f);
     so = origin; sd = dir;
@@ -192,7 +192,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     const int mtype = hr.mat_type;
     const float mparam = hr.param;
     v3 tex = V(hr.r, hr.g, hr.b);
-    if (TEX && hr.tex_dyn >= 0) tex = texture_eval(sc, hr, prim, origin, dir, t, 0.0f, hp, hn);  // checker / noise / image
+    if (TEX && hr.tex_dyn >= 0) tex = texture_eval(sc, hr, prim, origin, dir, t, 0.0f, hp, hn, noise_lds);  // checker / noise / image
     int ev;
     bool specular = false;
     if (mtype == RTW_MAT_LAMBERTIAN) {
@@ -465,13 +465,25 @@ RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, const TravMe
     A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
 }
 
+// LDS copy of one noise texture's tables (6 KB) for the kernels instantiated with TEX
+#define RTW_NOISE_SHARED __shared__ uint32_t s_noise[TEX ? 1536 : 1];
+template <bool TEX>
+RTW_DEV const uint32_t* stage_noise(const DScene& sc, uint32_t* s_noise) {
+    if (!TEX || sc.noise_lds_data < 0) return nullptr;
+    for (uint32_t i = threadIdx.x; i < 1536u; i += kBlock) s_noise[i] = sc.texdata[sc.noise_lds_data + i];
+    __syncthreads();
+    return s_noise;
+}
+
 // ------------------------------------------------------------------ k_first
 template <int KIND, bool TEX>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_CURSOR_SHARED
+    RTW_NOISE_SHARED
     const uint32_t tid = threadIdx.x;
     cursor_init(s_cursor);
+    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
@@ -544,7 +556,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             }
             v3 so, sd, att, radiance;
             Nee nee;
-            const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
+            const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee, noise_lds);
             n_seg++;
             if (nee.has) {
                 n_shadow++;
@@ -771,8 +783,10 @@ template <int KIND, bool TEX>
 __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A) {
     RTW_WORKLIST_SHARED
     RTW_CURSOR_SHARED
+    RTW_NOISE_SHARED
     const uint32_t tid = threadIdx.x;
     cursor_init(s_cursor);
+    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
     uint32_t n_seg = 0, n_shadow = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
     // the work-list lookup of the next chunk (a dependent chain of LDS reads) is issued behind this chunk's loads
@@ -811,7 +825,7 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
                 }
                 v3 so, sd, att, radiance;
                 Nee nee;
-                const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee);
+                const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee, noise_lds);
                 n_seg++;
                 p.ltmax = -1.0f;
                 if (nee.has) {
@@ -851,8 +865,10 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
     extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED
     RTW_CURSOR_SHARED
+    RTW_NOISE_SHARED
     const uint32_t tid = threadIdx.x;
     cursor_init(s_cursor);
+    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
@@ -890,7 +906,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                     traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, g, tm, t, prim);
                     v3 so, sd, att, radiance;
                     Nee nee;
-                    const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, t, prim, so, sd, att, radiance, nee);
+                    const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, t, prim, so, sd, att, radiance, nee, noise_lds);
                     n_seg++;
                     if (nee.has) {
                         float st;
