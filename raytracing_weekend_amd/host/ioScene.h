@@ -198,6 +198,46 @@ private:
                                              float(m_Nx) / float(m_Ny), /*aperture*/ 1.f, /*focus_distance*/ 10.f, 0.f, 1.f));
     }
 
+    // The 22 x 22 grid of small spheres of scenes 1 and 2 (ioScene.h:201-253, 373-422): one material draw, a jittered
+    // position, a keep-out zone around the medium spheres; 70 % diffuse (bobbing upwards by 0.18 in scene 1), 15 % metal,
+    // 8 % glass, 7 % hollow glass (two concentric spheres). Where the reference draws several randf() inside one
+    // argument list the order is unspecified C++; it only builds with MSVC, which evaluates arguments right
+    // to left, so colours are drawn blue, green, red and a metal's fuzz before its colour.
+    void scatterSmallSpheres(uint32_t seed, bool moving) {
+        const float r = 0.2f;
+        for (int a = -11; a < 11; a++) {
+            for (int b = -11; b < 11; b++) {
+                const float chooseMat = randf(seed);
+                const float x = a + 0.8f * randf(seed);
+                const float y = 0.2f;
+                const float z = b + 0.9f * randf(seed);
+                const float z_squared = z * z;
+                const float dist = sqrtf((x - 4.0f) * (x - 4.0f) + z_squared);
+                if (!((dist > 0.9f) || ((z_squared > 0.7f) && ((x * x - 16.0f) > -2.f)))) continue;
+                if (chooseMat < 0.70f) {
+                    if (moving) geometryList.emplace_back(new ioMovingSphere(x, y, z, x, y + 0.18f, z, r, 0.f, 1.f));
+                    else geometryList.emplace_back(new ioSphere(x, y, z, r));
+                    const float cb = randf(seed), cg = randf(seed), cr = randf(seed);
+                    materialList.push_back(mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))))));
+                } else if (chooseMat < 0.85f) {
+                    geometryList.emplace_back(new ioSphere(x, y, z, r));
+                    const float fuzz = 0.5f * randf(seed);
+                    const float cb = 0.5f * (1.0f - randf(seed));
+                    const float cg = 0.5f * (1.0f - randf(seed));
+                    const float cr = 0.5f * (1.0f - randf(seed));
+                    materialList.push_back(mat(new ioMetalMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))), fuzz)));
+                } else {
+                    geometryList.emplace_back(new ioSphere(x, y, z, r));
+                    materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+                    if (!(chooseMat < 0.93f)) {  // hollow: a second, slightly smaller glass sphere
+                        geometryList.emplace_back(new ioSphere(x, y, z, (r - 0.007f)));
+                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
+                    }
+                }
+            }
+        }
+    }
+
     // ---------------------------------------------------------------- scene 1
     void MovingSpheres() {
         sceneDescription = "InOneWeekend final scene with moving spheres";
@@ -214,42 +254,7 @@ private:
         materialList.push_back(mat(new ioLambertianMaterial(reddish)));
         materialList.push_back(mat(new ioMetalMaterial(fiftyPercentReddishGrey, 0.1f)));
 
-        // Small spheres, ioScene.h:201-253. Where the reference draws several randf() inside one
-        // argument list the order is unspecified C++; the reference only builds with
-        // MSVC, which evaluates arguments right to left, so that order is used here.
-        uint32_t seed = 0x314759;
-        for (int a = -11; a < 11; a++) {
-            for (int b = -11; b < 11; b++) {
-                float chooseMat = randf(seed);
-                float x = a + 0.8f * randf(seed);
-                float y = 0.2f;
-                float z = b + 0.9f * randf(seed);
-                float z_squared = z * z;
-                float dist = sqrtf((x - 4.0f) * (x - 4.0f) + z_squared);
-                if ((dist > 0.9f) || ((z_squared > 0.7f) && ((x * x - 16.0f) > -2.f))) {
-                    if (chooseMat < 0.70f) {
-                        geometryList.emplace_back(new ioMovingSphere(x, y, z, x, y + 0.18f, z, 0.2f, 0.f, 1.f));
-                        float cb = randf(seed), cg = randf(seed), cr = randf(seed);
-                        materialList.push_back(mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))))));
-                    } else if (chooseMat < 0.85f) {
-                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
-                        float fuzz = 0.5f * randf(seed);
-                        float cb = 0.5f * (1.0f - randf(seed));
-                        float cg = 0.5f * (1.0f - randf(seed));
-                        float cr = 0.5f * (1.0f - randf(seed));
-                        materialList.push_back(mat(new ioMetalMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))), fuzz)));
-                    } else if (chooseMat < 0.93f) {
-                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
-                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
-                    } else {
-                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
-                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
-                        geometryList.emplace_back(new ioSphere(x, y, z, (0.2f - 0.007f)));
-                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
-                    }
-                }
-            }
-        }
+        scatterSmallSpheres(0x314759, /*moving*/ true);  // ioScene.h:201-253
         identityInstances();
         camera.reset(new ioPerspectiveCamera(13.0f, 2.0f, 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 20.0f,
                                              float(m_Nx) / float(m_Ny), /*aperture*/ 0.1f, /*focus_distance*/ 10.f, 0.f, 1.f));
@@ -289,40 +294,7 @@ private:
         materialList.push_back(mat(new ioDiffuseLightMaterial(light16)));
         rectLight(make_float3(3.f, 1.f, -2.f), make_float3(5.f - 3.f, 0.f, 0.f), make_float3(0.f, 3.f - 1.f, 0.f), make_float3(16.f, 16.f, 16.f));
 
-        // small spheres, ioScene.h:373-422 (argument evaluation order as in scene 1: right to left, MSVC)
-        uint32_t seed = 0x6314759;
-        for (int a = -11; a < 11; a++) {
-            for (int b = -11; b < 11; b++) {
-                float chooseMat = randf(seed);
-                float x = a + 0.8f * randf(seed);
-                float y = 0.2f;
-                float z = b + 0.9f * randf(seed);
-                float z_squared = z * z;
-                float dist = sqrtf((x - 4.0f) * (x - 4.0f) + z_squared);
-                if ((dist > 0.9f) || ((z_squared > 0.7f) && ((x * x - 16.0f) > -2.f))) {
-                    if (chooseMat < 0.70f) {
-                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
-                        float cb = randf(seed), cg = randf(seed), cr = randf(seed);
-                        materialList.push_back(mat(new ioLambertianMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))))));
-                    } else if (chooseMat < 0.85f) {
-                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
-                        float fuzz = 0.5f * randf(seed);
-                        float cb = 0.5f * (1.0f - randf(seed));
-                        float cg = 0.5f * (1.0f - randf(seed));
-                        float cr = 0.5f * (1.0f - randf(seed));
-                        materialList.push_back(mat(new ioMetalMaterial(tex(new ioConstantTexture(make_float3(cr, cg, cb))), fuzz)));
-                    } else if (chooseMat < 0.93f) {
-                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
-                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
-                    } else {
-                        geometryList.emplace_back(new ioSphere(x, y, z, 0.2f));
-                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
-                        geometryList.emplace_back(new ioSphere(x, y, z, (0.2f - 0.007f)));
-                        materialList.push_back(mat(new ioDielectricMaterial(1.5f)));
-                    }
-                }
-            }
-        }
+        scatterSmallSpheres(0x6314759, /*moving*/ false);  // ioScene.h:373-422
         identityInstances();
         camera.reset(new ioPerspectiveCamera(13.0f, 2.0f, 3.0f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 20.0f,
                                              float(m_Nx) / float(m_Ny), /*aperture*/ 0.08f, /*focus_distance*/ 10.f));
