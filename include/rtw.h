@@ -180,6 +180,20 @@ typedef struct rtw_scene_header {
     rtw_pdf pdf;
 } rtw_scene_header;
 
+/* Estimators. The default reproduces the reference, including what makes its images
+ * physically off: the stray factor 2 in the cosine sampler, light samples weighted by the power heuristic
+ * while emitter hits are counted in full (Q3), the pdf rectangle of the scene instead of the chosen light's own (Q12,
+ * and every light but the first), an un-normalised incoming direction in the metal reflection (Q5).
+ * RTW_EST_CORRECTED fixes those: cosine-weighted scattering, each listed light sampled over its own parallelogram with
+ * the plain area-measure estimator, emitter hits of listed lights counted only where no light sample stood in for them.
+ * RTW_EST_CORRECTED_NO_NEE is the same integrand estimated without light sampling (every emitter hit counts): slow to
+ * converge, but an independent check - both converge to the same image. */
+typedef enum rtw_estimator {
+    RTW_EST_REFERENCE = 0,
+    RTW_EST_CORRECTED = 1,
+    RTW_EST_CORRECTED_NO_NEE = 2
+} rtw_estimator;
+
 typedef struct rtw_params {
     int32_t width, height;     /* full image (launch dimensions of the reference's optixLaunch) */
     int32_t spp;               /* samples per pixel rendered by this call                       */
@@ -192,7 +206,7 @@ typedef struct rtw_params {
     int32_t row_stride;        /* 0 or 1: every row of [row0,row1). k > 1: rows row0, row0+k, row0+2k ... < row1
                                   (interleaved shard: rank g of N uses row0=g, row1=height, row_stride=N, which
                                   balances the ranks); the output holds those rows consecutively               */
-    int32_t reserved;
+    int32_t estimator;         /* rtw_estimator: 0 = the reference's estimator, quirks and all (the parity mode)  */
 } rtw_params;
 
 /* kernels of the wavefront loop, index into the per-kernel arrays of rtw_stats */

@@ -230,6 +230,10 @@ typedef struct {
     const rtw_light* lights;
     const uint32_t* texdata; /* texture data section, texdata_words 4-byte words */
     uint32_t texdata_words;
+    /* RTW_EST_CORRECTED only (corrected_lights_build): the light list moved onto the emitting rectangles it describes,
+     * and which primitives those are */
+    rtw_light* clights;
+    uint8_t* listed;
 } scene_t;
 
 static int scene_open(scene_t* s, const void* blob, size_t bytes) {
@@ -245,6 +249,8 @@ static int scene_open(scene_t* s, const void* blob, size_t bytes) {
     if ((size_t)h->off_lights + (size_t)h->n_lights * sizeof(rtw_light) > bytes) return RTW_ERR_BAD_SCENE;
     if (h->n_xforms < 1) return RTW_ERR_BAD_SCENE;
     s->h = h;
+    s->clights = NULL;
+    s->listed = NULL;
     s->prims = (const rtw_prim*)(b + h->off_prims);
     s->xforms = (const rtw_xform*)(b + h->off_xforms);
     s->mats = (const rtw_material*)(b + h->off_materials);
@@ -701,7 +707,51 @@ typedef struct {
 enum { EV_MISS = 0, EV_HIT = 1, EV_FINISH = 2, EV_CANCEL = 3 };
 
 /* One camera path: raygen.cu:123-147 (one sample) + color :89-105 + rayColor :28-87. */
+/* RTW_EST_CORRECTED. A light definition describes an emitting rectangle of the scene (Director.cpp:527-530 fills the
+ * list by hand next to the geometry), but not always exactly: the Cornell box's light primitive sits at y = 554.9, its
+ * definition at y = 554. The corrected estimator samples the geometry that emits: definition i is matched
+ * to the untransformed emitting rectangle with the same normal axis and in-plane extent whose plane lies within 1 % of
+ * the longer edge, and moved onto that plane; emitter hits on matched primitives are what light samples stand in for. */
+static int corrected_lights_build(scene_t* sc) {
+    const uint32_t nl = sc->h->n_lights, np = sc->h->n_prims;
+    sc->clights = (rtw_light*)malloc((nl ? nl : 1) * sizeof(rtw_light));
+    sc->listed = (uint8_t*)calloc(np ? np : 1, 1);
+    if (!sc->clights || !sc->listed) return RTW_ERR_OOM;
+    for (uint32_t i = 0; i < nl; i++) {
+        rtw_light lt = sc->lights[i];
+        for (uint32_t j = 0; j < np; j++) {
+            const rtw_prim* pr = &sc->prims[j];
+            if (pr->type < RTW_PRIM_RECT_X || pr->type > RTW_PRIM_RECT_Z || pr->xform != 0) continue;
+            if (sc->mats[pr->material].type != RTW_MAT_DIFFUSE_LIGHT) continue;
+            const int ax = pr->type - RTW_PRIM_RECT_X;                 /* normal axis */
+            const int aa = ax == 0 ? 1 : 0, ab = ax == 2 ? 1 : 2;      /* in-plane axes a, b */
+            const float ea = pr->p[1] - pr->p[0], eb = pr->p[3] - pr->p[2];
+            float u[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+            u[aa] = ea; v[ab] = eb;
+            int same = lt.position[aa] == pr->p[0] && lt.position[ab] == pr->p[2];
+            for (int k = 0; k < 3; k++) if (lt.vec_u[k] != u[k] || lt.vec_v[k] != v[k]) same = 0;
+            if (!same || !(fabsf(lt.position[ax] - pr->p[4]) <= 0.01f * fmaxf(ea, eb))) continue;
+            lt.position[ax] = pr->p[4];
+            sc->listed[j] = 1;
+            break;
+        }
+        sc->clights[i] = lt;
+    }
+    return RTW_OK;
+}
+static void corrected_lights_free(scene_t* sc) {
+    free(sc->clights); free(sc->listed);
+    sc->clights = NULL; sc->listed = NULL;
+}
+
 static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int sample, counters_t* cn) {
+    const int est = P->estimator;
+    int nee_prev = 0; /* RTW_EST_CORRECTED: a light sample was taken at the previous vertex */
+    /* Ray epsilons. The reference starts scattered rays at t = 1e-6 from a hit point that is itself only accurate to
+     * ~2e-5 in a 555-unit scene: about half of the rays leaving a surface re-hit it at once (the surface then
+     * scatters twice). The corrected estimators start rays and end shadow probes 1e-3 away. */
+    const float ray_tmin = est ? 1.0e-3f : 1e-6f;
+    const float probe_eps = est ? 1.0e-3f : 500 * 1.0e-7f;
     const rtw_scene_header* H = sc->h;
     const rtw_camera* cam = &H->camera;
     rng_t g;
@@ -752,7 +802,7 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
     while (depth < P->max_depth) {
         float ray_time = rng_next(&g, 2); /* raygen.cu:48 */
         hit_t h;
-        traverse(sc, origin, dir, 1e-6f, 1.e27f, ray_time, gather_time, &g, 0, 0, &h);
+        traverse(sc, origin, dir, ray_tmin, 1.e27f, ray_time, gather_time, &g, 0, 0, &h);
         cn->segments++;
         v3 radiance = V(0.f, 0.f, 0.f);
         int ev;
@@ -788,8 +838,8 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
                 float sn, cs;
                 rtwo_sincos2pi(r1, &sn, &cs);
                 float sq = sqrtf(r2);
-                float lx = (cs * 2.0f) * sq;
-                float ly = (sn * 2.0f) * sq;
+                float lx = est ? cs * sq : (cs * 2.0f) * sq; /* corrected: cosine-weighted, without the stray 2 (Q1) */
+                float ly = est ? sn * sq : (sn * 2.0f) * sq;
                 float lz = sqrtf(1.0f - r2);
                 float pdf = lz * RTW_1_PI_F;
                 v3 sdir = V(fmaf(lz, w.x, fmaf(ly, v.x, lx * u.x)),
@@ -806,13 +856,15 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
             case RTW_MAT_DIFFUSE_LIGHT: {
                 /* material/diffuseLight.cu:48-69 */
                 if (dot3(hn, dir) < 0.0f) radiance = texture_value(sc, m, tu, tv, hp);
+                /* corrected: the light sample of the previous vertex already accounted for this emitter */
+                if (est == RTW_EST_CORRECTED && nee_prev && sc->listed[h.prim]) radiance = V(0.f, 0.f, 0.f);
                 ev = EV_CANCEL;
                 break;
             }
             case RTW_MAT_METAL: {
                 /* material/metalMaterial.cu:32-64 (Q5: direction is not normalised) */
                 specular = 1;
-                v3 refl = reflect3(dir, hn);
+                v3 refl = reflect3(est ? normalize3(dir) : dir, hn); /* corrected: unit incoming direction (Q5) */
                 v3 ball = random_in_unit_sphere(&g);
                 v3 sdir = normalize3(vfma(ball, m->fuzz_or_eta, refl));
                 so = hp; sd = sdir;
@@ -874,7 +926,41 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
             }
             /* next-event estimation: closehit.cu:70-118 */
             int nl = (int)H->n_lights;
-            if (ev == EV_HIT && !specular && nl > 0) {
+            nee_prev = 0;
+            if (est == RTW_EST_CORRECTED && ev == EV_HIT && !specular && nl > 0) {
+                /* each listed light over its own parallelogram, area-measure estimator, no heuristic weight */
+                nee_prev = 1;
+                int il = 0;
+                if (nl > 1) {
+                    il = (int)floorf(rng_next(&g, 1) * (float)nl);
+                    if (il < 0) il = 0;
+                    if (il > nl - 1) il = nl - 1;
+                }
+                const rtw_light* lt = &sc->clights[il];
+                float ra = rng_next(&g, 1);
+                float rb = rng_next(&g, 1);
+                v3 rp = vfma(ld3(lt->vec_v), rb, vfma(ld3(lt->vec_u), ra, ld3(lt->position)));
+                v3 ldir = vsub(rp, so);
+                float ldist = length3(ldir);
+                if (ldist > 1.0e-6f && m->bsdf_eval == 0) {
+                    ldir = vscale(ldir, 1.0f / ldist);
+                    float costa = dot3(vneg(ldir), ld3(lt->normal));
+                    float ndl = dot3(ldir, hn);
+                    v3 f = vscale(att, RTW_1_PI_F);
+                    if (costa > 1.0e-6f && ndl > 0.0f && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f)) {
+                        const float eps = probe_eps;
+                        hit_t sh;
+                        traverse(sc, so, ldir, eps, ldist - eps, 0.0f, gather_time, &g, 1, 0, &sh);
+                        cn->shadow_rays++;
+                        if (sh.prim < 0) {
+                            float lpdf = (ldist * ldist) / (lt->area * costa);
+                            float k = ndl / lpdf;
+                            v3 lem = vscale(ld3(lt->emission), (float)nl);
+                            radiance = vadd(radiance, vscale(vmul(f, lem), k));
+                        }
+                    }
+                }
+            } else if (est == RTW_EST_REFERENCE && ev == EV_HIT && !specular && nl > 0) {
                 int il = 0;
                 if (nl > 1) {
                     il = (int)floorf(rng_next(&g, 1) * (float)nl);
@@ -985,6 +1071,7 @@ static int check_params(const rtw_params* P) {
     if (!P || P->width <= 0 || P->height <= 0 || P->spp <= 0 || P->max_depth < 0) return RTW_ERR_INVALID_ARG;
     if (P->row0 < 0 || P->row1 > P->height || P->row0 > P->row1 || P->row_stride < 0) return RTW_ERR_INVALID_ARG;
     if (P->rng_kind != RTW_RNG_PHILOX && P->rng_kind != RTW_RNG_TEA_LCG) return RTW_ERR_INVALID_ARG;
+    if (P->estimator < RTW_EST_REFERENCE || P->estimator > RTW_EST_CORRECTED_NO_NEE) return RTW_ERR_INVALID_ARG;
     return RTW_OK;
 }
 
@@ -996,13 +1083,14 @@ int rtwo_render(const void* blob, size_t bytes, const rtw_params* P, float* rgba
     rc = check_params(P);
     if (rc) return rc;
     if (!rgba_out) return RTW_ERR_INVALID_ARG;
+    if (P->estimator == RTW_EST_CORRECTED && (rc = corrected_lights_build(&sc)) != RTW_OK) { corrected_lights_free(&sc); return rc; }
     int rows = local_rows_of(P);
     if (threads < 1) threads = 1;
     if (threads > rows) threads = rows > 0 ? rows : 1;
     if (threads > 256) threads = 256;
     job_t* jobs = (job_t*)calloc((size_t)threads, sizeof(job_t));
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));
-    if (!jobs || !th) { free(jobs); free(th); return RTW_ERR_OOM; }
+    if (!jobs || !th) { free(jobs); free(th); corrected_lights_free(&sc); return RTW_ERR_OOM; }
     for (int i = 0; i < threads; i++) {
         jobs[i].sc = &sc; jobs[i].P = P; jobs[i].out = rgba_out;
         jobs[i].r0 = (int)(((int64_t)rows * i) / threads);
@@ -1021,6 +1109,7 @@ int rtwo_render(const void* blob, size_t bytes, const rtw_params* P, float* rgba
         st->algorithmic_bytes = 128u * st->segments + 32u * st->samples;
     }
     free(jobs); free(th);
+    corrected_lights_free(&sc);
     return RTW_OK;
 }
 
@@ -1049,7 +1138,9 @@ int rtwo_trace_pixel(const void* blob, size_t bytes, const rtw_params* P, int px
     int rc = scene_open(&sc, blob, bytes);
     if (rc) return rc;
     counters_t cn = {0, 0};
+    if (P->estimator == RTW_EST_CORRECTED && (rc = corrected_lights_build(&sc)) != RTW_OK) { corrected_lights_free(&sc); return rc; }
     v3 L = trace_path(&sc, P, px, py, sample, &cn);
+    corrected_lights_free(&sc);
     rgb_out[0] = L.x; rgb_out[1] = L.y; rgb_out[2] = L.z;
     return RTW_OK;
 }

@@ -18,6 +18,7 @@ RTW_ABI_VERSION = 1
 RTW_SCENE_MAGIC = 0x57545221
 RTW_RNG_PHILOX = 0
 RTW_RNG_TEA_LCG = 1
+RTW_EST_REFERENCE, RTW_EST_CORRECTED, RTW_EST_CORRECTED_NO_NEE = range(3)
 
 # rtw_prim_type
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_RECT_X, PRIM_RECT_Y, PRIM_RECT_Z, PRIM_VOLUME_BOX, PRIM_VOLUME_SPHERE = range(7)
@@ -76,7 +77,7 @@ class SceneHeader(C.Structure):
 class Params(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("spp", C.c_int32), ("max_depth", C.c_int32),
                 ("seed", C.c_uint32), ("row0", C.c_int32), ("row1", C.c_int32), ("rng_kind", C.c_int32),
-                ("sample_offset", C.c_int32), ("samples_per_pass", C.c_int32), ("row_stride", C.c_int32), ("reserved", C.c_int32)]
+                ("sample_offset", C.c_int32), ("samples_per_pass", C.c_int32), ("row_stride", C.c_int32), ("estimator", C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -196,7 +197,7 @@ def assemble_scene(parts):
 
 
 def make_params(width, height, spp, max_depth, seed=0x6314759, row0=0, row1=None, rng_kind=RTW_RNG_PHILOX,
-                sample_offset=0, samples_per_pass=0, row_stride=0):
+                sample_offset=0, samples_per_pass=0, row_stride=0, estimator=0):
     p = Params()
     p.width, p.height, p.spp, p.max_depth = width, height, spp, max_depth
     p.seed = seed
@@ -206,6 +207,7 @@ def make_params(width, height, spp, max_depth, seed=0x6314759, row0=0, row1=None
     p.sample_offset = sample_offset
     p.samples_per_pass = samples_per_pass
     p.row_stride = row_stride
+    p.estimator = estimator
     return p
 
 

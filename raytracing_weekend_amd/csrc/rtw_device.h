@@ -300,7 +300,7 @@ struct HitRec {
     int32_t mat_type;   // rtw_material_type
     int32_t bsdf_eval;
     float param;        // fuzz or eta
-    int32_t kind;       // HK_* | (index of a non-constant texture + 1) << 8
+    int32_t kind;       // HK_* | listed light << 7 | (index of a non-constant texture + 1) << 8
     float r, g, b;      // texture colour
     float inv_r;        // spheres: 1/radius (IEEE division, done once on the host)
     float nx, ny, nz;   // HK_CONST_NORMAL: world shading normal (rectangles, volumes); spheres: centre
@@ -308,7 +308,7 @@ struct HitRec {
     // HK_CONST_NORMAL: the orthonormal basis onb::buildFromW(normal) of lib/onb.cuh:20-32, computed once on the
     // host with the same fp32 operations (u = cross(w,v), v = normalize(cross(w,a)), w = normalize(n))
     float ux, uy, uz; int32_t tex_dyn;  // (filled by load_hitrec from kind's high bits; -1 = constant colour in r, g, b)
-    float vx, vy, vz, pad1;
+    float vx, vy, vz; int32_t listed;    // (from kind bit 7) an emitting rectangle a light definition describes
     float wx, wy, wz, pad2;
 };
 
@@ -341,8 +341,12 @@ struct DScene {
     const uint32_t* __restrict__ texdata;    // noise tables, image texels (rtw.h rtw_texture)
     int32_t n_prims, n_vol, n_tree, n_lights, sky_light, use_bvh, has_motion, n_groups;
     int32_t n_generic;                       // order[n_vol .. n_vol+n_generic): moving spheres, tested through the generic path
-    int32_t n_lds_nodes, stack_depth, has_tex, noise_lds_data;  // noise_lds_data: word offset of the noise tables staged in LDS, or -1
-    int32_t pad3;  // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks
+    // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks; noise_lds_data: word offset of the
+    // noise tables staged in LDS, or -1
+    int32_t n_lds_nodes, stack_depth, has_tex, noise_lds_data;
+    int32_t estimator;                       // rtw_estimator of the current render (set per call, not at upload)
+    float ray_tmin, probe_eps;               // 1e-6 / 5e-5 as the reference; 1e-3 for the corrected estimators
+    const rtw_light* __restrict__ clights;   // RTW_EST_CORRECTED: the light list moved onto the emitting rectangles
     float bmin[3], bmax[3];                  // generous world bounds of everything (k_first's wave-uniform miss test)
     rtw_camera cam;
     rtw_pdf pdf;
@@ -747,7 +751,7 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
 // Only for scenes without volume or moving-sphere candidates (n_vol == 0 && n_generic == 0).
 RTW_DEV void traverse_dual_brute(const DScene& sc, const v3 o, const v3 dr, const v3 ds, const bool do_r, const bool do_s,
                                  const float smin, const float smax, float& best_t, int& best_prim, bool& occluded) {
-    const float rmin = 1e-6f;
+    const float rmin = sc.ray_tmin;
     best_t = 1.e27f;
     best_prim = -1;
     occluded = false;
@@ -809,11 +813,11 @@ RTW_DEV HitRec load_hitrec(const DScene& sc, int prim) {
     const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.hitrec + prim);
     const u32x4 a = q[0], b = q[1], c = q[2];
     HitRec h;
-    h.mat_type = (int)a.x; h.bsdf_eval = (int)a.y; h.param = __uint_as_float(a.z); h.kind = (int)(a.w & 255u); h.tex_dyn = (int)(a.w >> 8) - 1;
+    h.mat_type = (int)a.x; h.bsdf_eval = (int)a.y; h.param = __uint_as_float(a.z); h.kind = (int)(a.w & 127u); h.listed = (int)((a.w >> 7) & 1u); h.tex_dyn = (int)(a.w >> 8) - 1;
     h.r = __uint_as_float(b.x); h.g = __uint_as_float(b.y); h.b = __uint_as_float(b.z); h.inv_r = __uint_as_float(b.w);
     h.nx = __uint_as_float(c.x); h.ny = __uint_as_float(c.y); h.nz = __uint_as_float(c.z); h.xform = (int)c.w;
     h.ux = h.uy = h.uz = h.vx = h.vy = h.vz = h.wx = h.wy = h.wz = 0.f;
-    h.pad1 = h.pad2 = 0.f;
+    h.pad2 = 0.f;
     if (h.kind == HK_CONST_NORMAL && h.mat_type == RTW_MAT_LAMBERTIAN) {
         const u32x4 d = q[3], e = q[4], f = q[5];
         h.ux = __uint_as_float(d.x); h.uy = __uint_as_float(d.y); h.uz = __uint_as_float(d.z);

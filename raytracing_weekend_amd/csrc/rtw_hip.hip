@@ -320,6 +320,28 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
             return fail(c, RTW_ERR_BAD_SCENE, "unknown texture type");
         }
     }
+    // RTW_EST_CORRECTED: light definitions moved onto the emitting rectangles they describe, and which primitives those
+    // are (same matching rule as the CPU checker: same normal axis and in-plane extent, plane within 1 % of the longer edge)
+    std::vector<rtw_light> clights(lights);
+    std::vector<uint8_t> listed(h.n_prims, 0);
+    for (size_t i = 0; i < clights.size(); i++) {
+        rtw_light& lt = clights[i];
+        for (uint32_t j = 0; j < h.n_prims; j++) {
+            const rtw_prim& pr = prims[j];
+            if (pr.type < RTW_PRIM_RECT_X || pr.type > RTW_PRIM_RECT_Z || pr.xform != 0) continue;
+            if (pr.material < 0 || (uint32_t)pr.material >= h.n_materials || mats[pr.material].type != RTW_MAT_DIFFUSE_LIGHT) continue;
+            const int ax = pr.type - RTW_PRIM_RECT_X, aa = ax == 0 ? 1 : 0, ab = ax == 2 ? 1 : 2;
+            const float ea = pr.p[1] - pr.p[0], eb = pr.p[3] - pr.p[2];
+            float u[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+            u[aa] = ea; v[ab] = eb;
+            bool same = lt.position[aa] == pr.p[0] && lt.position[ab] == pr.p[2];
+            for (int k = 0; k < 3; k++) if (lt.vec_u[k] != u[k] || lt.vec_v[k] != v[k]) same = false;
+            if (!same || !(std::fabs(lt.position[ax] - pr.p[4]) <= 0.01f * std::fmax(ea, eb))) continue;
+            lt.position[ax] = pr.p[4];
+            listed[j] = 1;
+            break;
+        }
+    }
     std::vector<HitRec> shade(h.n_prims);
     std::vector<int32_t> order;
     int has_motion = 0, has_tex = 0;
@@ -386,6 +408,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
             if (t.type == RTW_TEX_CONSTANT) { s.r = t.color[0]; s.g = t.color[1]; s.b = t.color[2]; }
             else if (t.type != RTW_TEX_NULL) { s.kind |= (m.texture + 1) << 8; has_tex = 1; }  // checker / noise / image: evaluated per hit
         }
+        if (listed[i]) s.kind |= 0x80;
         shade[i] = s;
     }
     const Tuning tune = read_tuning();
@@ -439,7 +462,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     size_t o_xf = al(o_prims + prims.size() * sizeof(rtw_prim));
     size_t o_shade = al(o_xf + xforms.size() * sizeof(rtw_xform));
     size_t o_lights = al(o_shade + shade.size() * sizeof(HitRec));
-    size_t o_nodes = al(o_lights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
+    size_t o_clights = al(o_lights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
+    size_t o_nodes = al(o_clights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
     size_t o_tree = al(o_nodes + std::max<size_t>(1, bvh.wide.size()) * sizeof(BvhNode));
     size_t o_order = al(o_tree + std::max<size_t>(1, bvh.prim_order.size()) * sizeof(int32_t));
     size_t o_groups = al(o_order + std::max<size_t>(1, order.size()) * sizeof(int32_t));
@@ -452,6 +476,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     memcpy(stage.data() + o_xf, xforms.data(), xforms.size() * sizeof(rtw_xform));
     if (!shade.empty()) memcpy(stage.data() + o_shade, shade.data(), shade.size() * sizeof(HitRec));
     if (!lights.empty()) memcpy(stage.data() + o_lights, lights.data(), lights.size() * sizeof(rtw_light));
+    if (!clights.empty()) memcpy(stage.data() + o_clights, clights.data(), clights.size() * sizeof(rtw_light));
     static_assert(sizeof(BvhNode) == sizeof(rtwbvh::WideNode), "node layout");
     if (!bvh.wide.empty()) memcpy(stage.data() + o_nodes, bvh.wide.data(), bvh.wide.size() * sizeof(BvhNode));
     if (!bvh.prim_order.empty()) memcpy(stage.data() + o_tree, bvh.prim_order.data(), bvh.prim_order.size() * sizeof(int32_t));
@@ -473,6 +498,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.xforms = (const rtw_xform*)(d + o_xf);
     sc.hitrec = (const HitRec*)(d + o_shade);
     sc.lights = (const rtw_light*)(d + o_lights);
+    sc.clights = (const rtw_light*)(d + o_clights);
+    sc.estimator = RTW_EST_REFERENCE; sc.ray_tmin = 1e-6f; sc.probe_eps = 500 * 1.0e-7f;  // set per render
     sc.nodes = (const BvhNode*)(d + o_nodes);
     sc.tree_prims = (const int32_t*)(d + o_tree);
     sc.order = (const int32_t*)(d + o_order);
@@ -533,6 +560,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         return fail(c, RTW_ERR_INVALID_ARG, "bad render params");
     if (P->rng_kind != RTW_RNG_PHILOX && P->rng_kind != RTW_RNG_TEA_LCG) return fail(c, RTW_ERR_INVALID_ARG, "bad rng_kind");
     if (P->sample_offset < 0 || P->samples_per_pass < 0 || P->row_stride < 0) return fail(c, RTW_ERR_INVALID_ARG, "bad sample_offset/samples_per_pass/row_stride");
+    if (P->estimator < RTW_EST_REFERENCE || P->estimator > RTW_EST_CORRECTED_NO_NEE) return fail(c, RTW_ERR_INVALID_ARG, "bad estimator");
     HIP_TRY(c, hipSetDevice(c->device));
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
 
@@ -662,6 +690,10 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             HIP_TRY_C(hipMemsetAsync(L.cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), ls));
             KArgs a{};
             a.sc = c->sc;
+            if (P->estimator != RTW_EST_REFERENCE) {  // the corrected estimators live in the cold-feature instantiations
+                a.sc.estimator = P->estimator; a.sc.has_tex = 1;
+                a.sc.ray_tmin = 1.0e-3f; a.sc.probe_eps = 1.0e-3f;
+            }
             a.lbuf = L.lbuf;
             a.stats = c->d_stats;
             a.n_regions = regions;

@@ -33,6 +33,7 @@ using namespace rtwdev;
 constexpr int kBlock = 256;                       // 4 wave64 per workgroup
 constexpr uint32_t kMaxRegions = 2048;            // region counters scanned in LDS by every workgroup (>= the compacting grid)
 constexpr uint32_t kZombie = 0x80000000u;
+constexpr uint32_t kNeePrev = 0x40000000u;       // gk bit 30 (corrected estimator): a light sample was taken at the previous vertex
 
 struct PathBuf {
     float4* p0; float4* p1; float4* p2; float4* p3; float4* p4; uint4* p5;
@@ -169,7 +170,11 @@ struct Nee {
 // TEX: the instantiation for scenes with non-constant textures or media (the cold features)
 template <int KIND, bool TEX>
 RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 dir, const float gather_time, const float t, const int prim,
-                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee, const uint32_t* noise_lds) {
+                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee, const uint32_t* noise_lds, uint32_t& nee_prev) {
+    // nee_prev (corrected estimator only): in - a light sample was taken at the previous vertex; out - one was taken here
+    const int est = TEX ? sc.estimator : 0;
+    const uint32_t had_nee = nee_prev;
+    nee_prev = 0u;
     radiance = V(0.f, 0.f, 0.f);
     att = V(0.f, 0.f, 0.f);
     so = origin; sd = dir;
@@ -211,8 +216,8 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         float sn, cs;
         sincos2pi(r1, sn, cs);
         float sq = __builtin_sqrtf(r2);
-        float lx = (cs * 2.0f) * sq;
-        float ly = (sn * 2.0f) * sq;
+        float lx = est ? cs * sq : (cs * 2.0f) * sq;  // corrected: cosine-weighted, without the stray 2 (Q1)
+        float ly = est ? sn * sq : (sn * 2.0f) * sq;
         float lz = __builtin_sqrtf(1.0f - r2);
         float pdf = lz * RTW_1_PI_F;
         v3 sdir = V(fma_(lz, w.x, fma_(ly, v.x, lx * u.x)),
@@ -227,11 +232,13 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     } else if (mtype == RTW_MAT_DIFFUSE_LIGHT) {
         // diffuseLight.cu:48-69
         if (dot3(hn, dir) < 0.0f) radiance = tex;
+        // corrected: the light sample of the previous vertex already accounted for this emitter
+        if (est == RTW_EST_CORRECTED && had_nee != 0u && hr.listed != 0) radiance = V(0.f, 0.f, 0.f);
         ev = EV_CANCEL;
     } else if (mtype == RTW_MAT_METAL) {
         // metalMaterial.cu:32-64 (Q5)
         specular = true;
-        v3 refl = reflect3(dir, hn);
+        v3 refl = reflect3(est ? normalize3(dir) : dir, hn);  // corrected: unit incoming direction (Q5)
         v3 ball = random_in_unit_sphere(g);
         v3 sdir = normalize3(vfma(ball, mparam, refl));
         so = hp; sd = sdir;
@@ -286,7 +293,39 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
 
     // next-event estimation, closehit.cu:70-94: sample the light; the visibility probe comes later
     const int nl = sc.n_lights;
-    if (ev == EV_HIT && !specular && nl > 0) {
+    if (est == RTW_EST_CORRECTED && ev == EV_HIT && !specular && nl > 0) {
+        // each listed light over its own parallelogram (moved onto the emitting rectangle at upload), area-measure
+        // estimator, no heuristic weight
+        nee_prev = 1u;
+        int il = 0;
+        if (nl > 1) {
+            il = (int)__builtin_floorf(g.next1() * (float)nl);
+            il = il < 0 ? 0 : (il > nl - 1 ? nl - 1 : il);
+        }
+        const rtw_light lt = sc.clights[il];
+        const float ra = g.next1();
+        const float rb = g.next1();
+        const v3 rp = vfma(ld3(lt.vec_v), rb, vfma(ld3(lt.vec_u), ra, ld3(lt.position)));
+        v3 ldir = vsub(rp, so);
+        const float ldist = length3(ldir);
+        if (ldist > 1.0e-6f && hr.bsdf_eval == 0) {
+            ldir = vscale(ldir, 1.0f / ldist);
+            const float costa = dot3(vneg(ldir), ld3(lt.normal));
+            const float ndl = dot3(ldir, hn);
+            const v3 f = vscale(att, RTW_1_PI_F);
+            if (costa > 1.0e-6f && ndl > 0.0f && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f)) {
+                const float eps = sc.probe_eps;
+                const float lpdf = (ldist * ldist) / (lt.area * costa);
+                const float k = ndl / lpdf;
+                const v3 lem = vscale(ld3(lt.emission), (float)nl);
+                nee.has = true;
+                nee.dir = ldir;
+                nee.tmin = eps;
+                nee.tmax = ldist - eps;
+                nee.rad = vscale(vmul(f, lem), k);
+            }
+        }
+    } else if (est == RTW_EST_REFERENCE && ev == EV_HIT && !specular && nl > 0) {
         int il = 0;
         if (nl > 1) {
             il = (int)__builtin_floorf(g.next1() * (float)nl);
@@ -335,7 +374,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
             float ndl = dot3(ldir, hn);
             float bpdf = __builtin_fmaxf(0.0f, ndl * RTW_1_PI_F);
             if (0.0f < bpdf && (f.x != 0.0f || f.y != 0.0f || f.z != 0.0f)) {
-                const float eps = 500 * 1.0e-7f;
+                const float eps = sc.probe_eps;
                 float a2 = lpdf * lpdf;
                 float weight = a2 / fma_(bpdf, bpdf, a2);  // raydata.cuh:167-171
                 float k = (weight * ndl) / lpdf;
@@ -449,15 +488,15 @@ RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, const TravMe
     if (DUAL) {
         // small scenes: one shared walk for both rays
         bool oc;
-        traverse_dual_brute(A.sc, p.o, p.d, p.ldir, do_r, do_s, 500 * 1.0e-7f, p.ltmax, th, prim, oc);
+        traverse_dual_brute(A.sc, p.o, p.d, p.ldir, do_r, do_s, A.sc.probe_eps, p.ltmax, th, prim, oc);
         if (!do_r) { th = 0.f; prim = -1; }
         if (do_s) occl = (oc ? 0x80000000u : 0u) | 0x40000000u;  // bit 30: a probe was queued
     } else {
-        if (do_r) traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
+        if (do_r) traverse<NoRng, false, true>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
         if (do_s) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
             float st;
             int sprim;
-            traverse<NoRng, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, ng, tm, st, sprim);
+            traverse<NoRng, true, true>(A.sc, p.o, p.ldir, A.sc.probe_eps, p.ltmax, 0.0f, gt, ng, tm, st, sprim);
             occl = (sprim >= 0 ? 0x80000000u : 0u) | 0x40000000u;
         }
     }
@@ -551,12 +590,14 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             // and a wave-uniform test against the scene bounds spares them the walk over the candidate lists
             th = 1.e27f; prim = -1;
             if (__ballot(may_hit_scene(A.sc, p.o, p.d)) != 0ull) {
-                if (TEX && A.sc.n_vol > 0) traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, g, tm, th, prim);
-                else traverse<NoRng, false, true>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
+                if (TEX && A.sc.n_vol > 0) traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, g, tm, th, prim);
+                else traverse<NoRng, false, true>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
             }
             v3 so, sd, att, radiance;
             Nee nee;
-            const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee, noise_lds);
+            uint32_t nee_prev = 0u;
+            const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee, noise_lds, nee_prev);
+            if (nee_prev) p.gk |= kNeePrev;
             n_seg++;
             if (nee.has) {
                 n_shadow++;
@@ -688,9 +729,9 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
                     th = 0.f; prim = -1; occl = 0;
                     const bool do_r = !(p.gk & kZombie);
                     if (do_r) {
-                        d = p.d; tmin = 1e-6f; best_t = 1.e27f; ray_time = p.ray_time; shadow_phase = false;
+                        d = p.d; tmin = A.sc.ray_tmin; best_t = 1.e27f; ray_time = p.ray_time; shadow_phase = false;
                     } else {
-                        d = ldir; tmin = 500 * 1.0e-7f; best_t = ltmax; ray_time = 0.0f; shadow_phase = true;
+                        d = ldir; tmin = A.sc.probe_eps; best_t = ltmax; ray_time = 0.0f; shadow_phase = true;
                     }
                     inv = recip3(d);
                     best_prim = -1; sp = 0; cur = root;
@@ -752,7 +793,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
                 if (!shadow_phase) {
                     th = best_t; prim = best_prim;
                     if (ltmax >= 0.0f) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
-                        d = ldir; inv = recip3(d); tmin = 500 * 1.0e-7f; best_t = ltmax; ray_time = 0.0f;
+                        d = ldir; inv = recip3(d); tmin = A.sc.probe_eps; best_t = ltmax; ray_time = 0.0f;
                         best_prim = -1; sp = 0; cur = root; shadow_phase = true;
                         n_rays++;
                     } else {
@@ -821,11 +862,13 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
                     // generator lives, before this segment's closest-hit draws - the reference's order
                     float tv = 1.e27f;
                     int pv = -1;
-                    if (volume_pass<Rng<KIND>, false>(A.sc, p.o, p.d, 1e-6f, p.ray_time, gt, g, tv, pv) && !(prim >= 0 && th < tv)) { th = tv; prim = pv; }
+                    if (volume_pass<Rng<KIND>, false>(A.sc, p.o, p.d, A.sc.ray_tmin, p.ray_time, gt, g, tv, pv) && !(prim >= 0 && th < tv)) { th = tv; prim = pv; }
                 }
                 v3 so, sd, att, radiance;
                 Nee nee;
-                const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee, noise_lds);
+                uint32_t nee_prev = (p.gk & kNeePrev) ? 1u : 0u;
+                const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, th, prim, so, sd, att, radiance, nee, noise_lds, nee_prev);
+                p.gk = (p.gk & ~kNeePrev) | (nee_prev ? kNeePrev : 0u);
                 n_seg++;
                 p.ltmax = -1.0f;
                 if (nee.has) {
@@ -889,7 +932,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                                     // generator in the reference's draw order; what is left is the surfaces
                 float st;
                 int sprim;
-                traverse<Rng<KIND>, true, true>(A.sc, p.o, p.ldir, 500 * 1.0e-7f, p.ltmax, 0.0f, gt, g, tm, st, sprim);
+                traverse<Rng<KIND>, true, true>(A.sc, p.o, p.ldir, A.sc.probe_eps, p.ltmax, 0.0f, gt, g, tm, st, sprim);
                 if (sprim < 0) p.L = vadd(p.L, p.c);
                 p.ltmax = -1.0f;
             }
@@ -900,13 +943,14 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                 // longer launches win; scenes with volumes run every bounce here (n_iter = 1 while wide).
                 uint32_t depth = A.depth;
                 bool alive = false;
+                uint32_t nee_prev = (p.gk & kNeePrev) ? 1u : 0u;
                 for (uint32_t it = 0; it < A.n_iter; it++) {
                     float t;
                     int prim;
-                    traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, 1e-6f, 1.e27f, p.ray_time, gt, g, tm, t, prim);
+                    traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, g, tm, t, prim);
                     v3 so, sd, att, radiance;
                     Nee nee;
-                    const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, t, prim, so, sd, att, radiance, nee, noise_lds);
+                    const int ev = shade_a<KIND, TEX>(A.sc, g, p.o, p.d, gt, t, prim, so, sd, att, radiance, nee, noise_lds, nee_prev);
                     n_seg++;
                     if (nee.has) {
                         float st;
@@ -921,6 +965,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                     p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(depth) : 0.0f;
                 }
                 p.a = g.a; p.b = g.b;
+                p.gk = (p.gk & ~kNeePrev) | (nee_prev ? kNeePrev : 0u);
                 if (alive) keep = true;
                 else finish_path(A, path_id_of<KIND>(A, p), p.L);
             }

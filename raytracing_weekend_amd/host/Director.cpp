@@ -61,6 +61,7 @@ void Director::renderFrame() {
     p.row0 = 0;
     p.row1 = m_Ny;
     p.rng_kind = m_rngKind;
+    p.estimator = m_estimator;
     int rc = rtw_render(m_ctx, &p, m_hostBuffer.data(), &m_stats);
     if (rc != RTW_OK) die(m_ctx, "rtw_render", rc);
     if (_verbose) {

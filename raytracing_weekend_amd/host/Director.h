@@ -30,6 +30,7 @@ public:
     void setSeed(uint32_t seed) { m_seed = seed; }
     void setRngKind(int kind) { m_rngKind = kind; }
     void setDevice(int device) { m_device = device; }
+    void setEstimator(int estimator) { m_estimator = estimator; }  // rtw_estimator
     const rtw_stats& stats() const { return m_stats; }
     const std::vector<float>& hostBuffer() const { return m_hostBuffer; }  // linear RGBA, row 0 = bottom row
 
@@ -41,6 +42,7 @@ private:
     uint32_t m_seed = 0x6314759u;
     int m_rngKind = RTW_RNG_PHILOX;
     int m_device = 0;
+    int m_estimator = RTW_EST_REFERENCE;
     rtw_ctx* m_ctx = nullptr;
     rtwhost::ioScene m_scene;
     std::vector<float> m_hostBuffer;

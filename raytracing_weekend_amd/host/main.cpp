@@ -57,6 +57,8 @@ int main(int argc, char* argv[]) {
     -d N           Maximum path depth (reference: 20)
     -seed N        RNG seed
     -rng K         philox (default) or lcg (the reference's tea+lcg generator)
+    -est K         reference (default: the reference's estimator, quirks included), corrected, or brute
+                   (corrected without light sampling)
     -gpu N         Device ordinal
     -o FILE        Write FILE instead of ASCII P3 on stdout: *.ppm = binary P6, *.png = 8-bit PNG, *.pfm = linear float PFM
 
@@ -88,11 +90,18 @@ int main(int argc, char* argv[]) {
     if (rngName == "lcg") rng = RTW_RNG_TEA_LCG;
     else if (!rngName.empty() && rngName != "philox") std::cerr << "WARNING: unknown -rng " << rngName << ", using philox" << std::endl;
 
+    int estimator = RTW_EST_REFERENCE;
+    const std::string& estName = cl_input.getCmdOption("-est");
+    if (estName == "corrected") estimator = RTW_EST_CORRECTED;
+    else if (estName == "brute") estimator = RTW_EST_CORRECTED_NO_NEE;
+    else if (!estName.empty() && estName != "reference") std::cerr << "WARNING: unknown -est " << estName << ", using reference" << std::endl;
+
     Director director(Qverbose, Qdebug);
     director.setDevice(gpu);
     director.setMaxDepth(depth);
     director.setSeed(seed);
     director.setRngKind(rng);
+    director.setEstimator(estimator);
 
     auto start = std::chrono::system_clock::now();
     director.init(Nx, Ny, Ns);

@@ -224,6 +224,49 @@ def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
         monkeypatch.delenv(n, raising=False)
 
 
+@pytest.mark.parametrize("est", [abi.RTW_EST_CORRECTED, abi.RTW_EST_CORRECTED_NO_NEE])
+def test_corrected_estimators_match_oracle(gpu, est):
+    """the corrected estimators (cosine sampling, per-light area sampling without the heuristic weight,
+    emitter hits not double counted, 1e-3 ray offsets) - bit-exact against the oracle like the reference mode."""
+    cases = [(abi.build_scene(0, 96, 64), 96, 64), (abi.build_scene(2, 80, 48), 80, 48), (abi.build_scene(4, 64, 40), 64, 40),
+             (oracle.random_scene(13, 72, 54, n_prims=24, n_lights=3), 72, 54),
+             (oracle.random_scene(18, 72, 54, n_prims=70, volumes=True, motion=True, n_lights=2), 72, 54)]
+    for blob, w, h in cases:
+        gpu.upload_scene(blob)
+        for rng in (abi.RTW_RNG_PHILOX, abi.RTW_RNG_TEA_LCG):
+            p = abi.make_params(w, h, 4, 30, rng_kind=rng, estimator=est)
+            img, st = gpu.render(p)
+            ref, st_ref = oracle.render(blob, p, threads=16)
+            check(img, ref, st, st_ref)
+    # the reference estimator is untouched by a corrected render in between
+    blob = abi.build_scene(0, 96, 64)
+    gpu.upload_scene(blob)
+    p = abi.make_params(96, 64, 4, 30)
+    img, st = gpu.render(p)
+    ref, st_ref = oracle.render(blob, p, threads=16)
+    check(img, ref, st, st_ref)
+
+
+def test_corrected_estimators_agree_with_each_other(gpu):
+    """Light sampling and brute-force emitter hits estimate the same integrand: at 16K / 128K samples per pixel the block
+    means of a 64x64 Cornell box agree within 2 %, the image means within 0.5 %; the reference estimator does not
+    (it is ~20 % darker in the mean: stray factor 2, self-intersections, heuristic weights without their complement)."""
+    w = h = 64
+    gpu.upload_scene(abi.build_scene(0, w, h))
+    nee, _ = gpu.render(abi.make_params(w, h, 16384, 50, estimator=abi.RTW_EST_CORRECTED))
+    brute, _ = gpu.render(abi.make_params(w, h, 131072, 50, estimator=abi.RTW_EST_CORRECTED_NO_NEE))
+    ref, _ = gpu.render(abi.make_params(w, h, 16384, 50))
+
+    def blocks(a):
+        return a[..., :3].astype(np.float64).reshape(8, 8, 8, 8, 3).mean(axis=(1, 3))
+    m_nee, m_brute, m_ref = (a[..., :3].astype(np.float64).mean() for a in (nee, brute, ref))
+    assert abs(m_nee - m_brute) / m_brute < 5e-3, (m_nee, m_brute)
+    lit = blocks(brute) > 0.02
+    rel = np.abs(blocks(nee) - blocks(brute))[lit] / blocks(brute)[lit]
+    assert rel.max() < 0.02, rel.max()
+    assert abs(m_ref - m_brute) / m_brute > 0.05
+
+
 def test_edge_cases(gpu):
     blob = abi.build_scene(0, 8, 8)
     gpu.upload_scene(blob)

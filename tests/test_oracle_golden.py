@@ -224,3 +224,25 @@ def test_corrupted_scenes_are_rejected_by_the_oracle():
     assert lib.rtwo_render(ok, len(ok), C.byref(p), out.ctypes.data, C.byref(st), 1) == 0
     for name, blob in oracle.corrupted_scenes():
         assert lib.rtwo_render(blob, len(blob), C.byref(p), out.ctypes.data, C.byref(st), 1) == -2, name
+
+
+def test_corrected_estimators_on_the_oracle():
+    """SURVEY 8f rank 2 on the CPU: the modes differ from the reference mode and from each other at low sample counts,
+    agree in the mean at moderate ones, bad estimator ids are refused, and the default (0) is the fixture mode."""
+    w, h = 24, 24
+    blob = abi.build_scene(0, w, h)
+    imgs = {}
+    for est, spp in ((0, 256), (1, 256), (2, 4096)):
+        img, st = oracle.render(blob, abi.make_params(w, h, spp, 50, estimator=est), threads=8)
+        assert np.isfinite(img).all()
+        assert (st.shadow_rays > 0) == (est != 2)
+        imgs[est] = img[..., :3].astype(np.float64)
+    m = {k: v.mean() for k, v in imgs.items()}
+    assert abs(m[1] - m[2]) / m[2] < 0.03, m          # two estimators, one integrand
+    assert abs(m[0] - m[2]) / m[2] > 0.05, m          # the reference's quirks are visible in the mean
+    lib = oracle.load()
+    out = np.zeros((h, w, 4), np.float32)
+    st = abi.Stats()
+    for bad in (-1, 3):
+        p = abi.make_params(w, h, 1, 2, estimator=bad)
+        assert lib.rtwo_render(blob, len(blob), C.byref(p), out.ctypes.data, C.byref(st), 1) == -1
