@@ -252,6 +252,15 @@ int rtw_destroy(rtw_ctx* ctx);
 
 const char* rtw_last_error(rtw_ctx* ctx);
 
+/* Stand-in for the reference's output stage, the OptiX AI denoiser (Director::initDenoiser, Director.cpp:887-949,
+ * invoked at :986-997 on the beauty layer alone, LDR model, no albedo / normal guides). The AI model is closed; this is
+ * an edge-avoiding a-trous wavelet filter on the same input (Dammertz et al. 2010, colour edge-stopping only):
+ * `iterations` passes with a 5x5 B3-spline kernel at hole sizes 1, 2, 4 ..., each tap weighted by
+ * 1 / (1 + |c_p - c_q|^2 / sigma_i^2), sigma_i = sigma * 2^-i. rgba_in / rgba_out: host, width*height float4, may not
+ * alias; alpha is copied. Meant for display-encoded values in [0, 1] (the reference's LDR model sees sqrt(colour));
+ * not part of rtw_render: 4096-spp frames need none. iterations in 1..8, sigma > 0. */
+int rtw_denoise(rtw_ctx* ctx, const float* rgba_in, float* rgba_out, int32_t width, int32_t height, int32_t iterations, float sigma);
+
 /* Test hooks (no reference counterpart): one closest-hit query per ray on the GPU accel structure,
  * used by the parity tests to compare BVH traversal with the oracle's brute force.
  * rays: n*8 floats (ox,oy,oz,dx,dy,dz,tmin,tmax); ray_time: n floats or NULL;

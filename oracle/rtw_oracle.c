@@ -1144,3 +1144,47 @@ int rtwo_trace_pixel(const void* blob, size_t bytes, const rtw_params* P, int px
     rgb_out[0] = L.x; rgb_out[1] = L.y; rgb_out[2] = L.z;
     return RTW_OK;
 }
+
+/* CPU restatement of rtw_denoise (include/rtw.h): the same taps, weights and order of operations. */
+int rtwo_denoise(const float* rgba_in, float* rgba_out, int width, int height, int iterations, float sigma) {
+    if (!rgba_in || !rgba_out || rgba_in == rgba_out || width <= 0 || height <= 0 || iterations < 1 || iterations > 8 || !(sigma > 0.f))
+        return RTW_ERR_INVALID_ARG;
+    const size_t n = (size_t)width * height;
+    float* buf[2] = {(float*)malloc(n * 16), (float*)malloc(n * 16)};
+    if (!buf[0] || !buf[1]) { free(buf[0]); free(buf[1]); return RTW_ERR_OOM; }
+    memcpy(buf[0], rgba_in, n * 16);
+    const float kern[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+    int cur = 0;
+    float s_i = sigma;
+    for (int it = 0; it < iterations; it++) {
+        const float* in = buf[cur];
+        float* out = buf[cur ^ 1];
+        const int step = 1 << it;
+        const float inv_sigma2 = 1.0f / (s_i * s_i);
+        for (int y = 0; y < height; y++)
+            for (int x = 0; x < width; x++) {
+                const float* c = in + 4 * ((size_t)y * width + x);
+                float sr = 0.f, sg = 0.f, sb = 0.f, sw = 0.f;
+                for (int dy = -2; dy <= 2; dy++) {
+                    int yy = y + dy * step;
+                    yy = yy < 0 ? 0 : (yy > height - 1 ? height - 1 : yy);
+                    for (int dx = -2; dx <= 2; dx++) {
+                        int xx = x + dx * step;
+                        xx = xx < 0 ? 0 : (xx > width - 1 ? width - 1 : xx);
+                        const float* q = in + 4 * ((size_t)yy * width + xx);
+                        const float dr = c[0] - q[0], dg = c[1] - q[1], db = c[2] - q[2];
+                        const float d2 = (dr * dr + dg * dg) + db * db;
+                        const float w = (kern[dy + 2] * kern[dx + 2]) / (1.0f + d2 * inv_sigma2);
+                        sr = sr + w * q[0]; sg = sg + w * q[1]; sb = sb + w * q[2]; sw = sw + w;
+                    }
+                }
+                float* o = out + 4 * ((size_t)y * width + x);
+                o[0] = sr / sw; o[1] = sg / sw; o[2] = sb / sw; o[3] = c[3];
+            }
+        cur ^= 1;
+        s_i = s_i * 0.5f;
+    }
+    memcpy(rgba_out, buf[cur], n * 16);
+    free(buf[0]); free(buf[1]);
+    return RTW_OK;
+}

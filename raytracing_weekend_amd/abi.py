@@ -93,7 +93,7 @@ class Stats(C.Structure):
 
 
 HIP_SYMBOLS = ["rtw_abi_version", "rtw_create", "rtw_upload_scene", "rtw_render", "rtw_render_device",
-               "rtw_destroy", "rtw_last_error", "rtw_debug_intersect"]
+               "rtw_destroy", "rtw_last_error", "rtw_debug_intersect", "rtw_denoise"]
 
 _host = None
 _hip = None
@@ -132,6 +132,8 @@ def load_hip():
         lib.rtw_destroy.argtypes = [C.c_void_p]
         lib.rtw_last_error.restype = C.c_char_p
         lib.rtw_last_error.argtypes = [C.c_void_p]
+        lib.rtw_denoise.restype = C.c_int
+        lib.rtw_denoise.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_float]
         lib.rtw_debug_intersect.restype = C.c_int
         lib.rtw_debug_intersect.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         if lib.rtw_abi_version() != RTW_ABI_VERSION:
@@ -248,6 +250,14 @@ class Renderer:
         self._check(self.lib.rtw_render_device(self.ctx, C.byref(params), C.c_void_p(device_ptr),
                                                C.c_void_p(stream_ptr), C.byref(st)), "rtw_render_device")
         return st
+
+    def denoise(self, img, iterations=5, sigma=0.5):
+        """rtw_denoise on an (h, w, 4) float32 image; returns the filtered image."""
+        src = np.ascontiguousarray(img, dtype=np.float32)
+        h, w = src.shape[:2]
+        out = np.empty_like(src)
+        self._check(self.lib.rtw_denoise(self.ctx, src.ctypes.data, out.ctypes.data, w, h, iterations, sigma), "rtw_denoise")
+        return out
 
     def debug_intersect(self, rays, ray_time=None, gather_time=None):
         rays = np.ascontiguousarray(rays, dtype=np.float32)

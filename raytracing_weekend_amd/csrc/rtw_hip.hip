@@ -808,6 +808,36 @@ int rtw_render(rtw_ctx* c, const rtw_params* P, float* rgba_out, rtw_stats* stat
     return RTW_OK;
 }
 
+int rtw_denoise(rtw_ctx* c, const float* rgba_in, float* rgba_out, int32_t width, int32_t height, int32_t iterations, float sigma) {
+    if (!c) return RTW_ERR_INVALID_ARG;
+    if (!rgba_in || !rgba_out || rgba_in == rgba_out || width <= 0 || height <= 0 || iterations < 1 || iterations > 8 || !(sigma > 0.f) ||
+        (int64_t)width * height > (1 << 28))
+        return fail(c, RTW_ERR_INVALID_ARG, "rtw_denoise: bad argument");
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t bytes = (size_t)width * height * sizeof(float4);
+    float4* d[2] = {nullptr, nullptr};
+    auto cleanup = [&]() { for (float4* p : d) if (p) (void)hipFree(p); };
+    for (int k = 0; k < 2; k++)
+        if (hipMalloc(&d[k], bytes) != hipSuccess) { cleanup(); return fail(c, RTW_ERR_OOM, "rtw_denoise: device allocation failed"); }
+    hipError_t e = hipMemcpyAsync(d[0], rgba_in, bytes, hipMemcpyHostToDevice, c->stream);
+    const int n = width * height;
+    const unsigned grid = (unsigned)std::min<int64_t>(((int64_t)n + kBlock - 1) / kBlock, (int64_t)c->n_cu * 8);
+    int cur = 0;
+    float s_i = sigma;
+    for (int it = 0; it < iterations && e == hipSuccess; it++) {
+        hipLaunchKernelGGL(k_atrous, dim3(grid), dim3(kBlock), 0, c->stream, (const float4*)d[cur], d[cur ^ 1], (int)width, (int)height, 1 << it,
+                           1.0f / (s_i * s_i));
+        e = hipGetLastError();
+        cur ^= 1;
+        s_i = s_i * 0.5f;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(rgba_out, d[cur], bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    cleanup();
+    if (e != hipSuccess) return fail(c, RTW_ERR_DEVICE, std::string("rtw_denoise: ") + hipGetErrorString(e));
+    return RTW_OK;
+}
+
 int rtw_debug_intersect(rtw_ctx* c, const float* rays, const float* ray_time, const float* gather_time, int n, float* out_t, int32_t* out_prim) {
     if (!c) return RTW_ERR_INVALID_ARG;
     if (!c->has_scene) return fail(c, RTW_ERR_NO_SCENE, "no scene");

@@ -975,6 +975,31 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
     cursor_publish(A, s_cursor, n_seg, n_shadow, RTW_K_BOUNCE);
 }
 
+// One a-trous pass (rtw.h rtw_denoise): 25 taps in row-major order, clamped at the borders, plain fp32 in a fixed order
+__global__ void __launch_bounds__(kBlock) k_atrous(const float4* __restrict__ in, float4* __restrict__ out, int width, int height, int step, float inv_sigma2) {
+    const int n = width * height;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int y = i / width, x = i - y * width;
+        const float4 c = in[i];
+        const float kern[5] = {1.0f / 16.0f, 1.0f / 4.0f, 3.0f / 8.0f, 1.0f / 4.0f, 1.0f / 16.0f};
+        float sr = 0.f, sg = 0.f, sb = 0.f, sw = 0.f;
+        for (int dy = -2; dy <= 2; dy++) {
+            int yy = y + dy * step;
+            yy = yy < 0 ? 0 : (yy > height - 1 ? height - 1 : yy);
+            for (int dx = -2; dx <= 2; dx++) {
+                int xx = x + dx * step;
+                xx = xx < 0 ? 0 : (xx > width - 1 ? width - 1 : xx);
+                const float4 q = in[yy * width + xx];
+                const float dr = c.x - q.x, dg = c.y - q.y, db = c.z - q.z;
+                const float d2 = (dr * dr + dg * dg) + db * db;
+                const float w = (kern[dy + 2] * kern[dx + 2]) / (1.0f + d2 * inv_sigma2);
+                sr = sr + w * q.x; sg = sg + w * q.y; sb = sb + w * q.z; sw = sw + w;
+            }
+        }
+        out[i] = make_float4(sr / sw, sg / sw, sb / sw, c.w);
+    }
+}
+
 // sums the S sample slots of every pixel in ascending sample order (fixed order => reproducible bits)
 __global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ lbuf, float4* __restrict__ accum, uint32_t npix, uint32_t nslots) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {

@@ -64,6 +64,20 @@ void Director::renderFrame() {
     p.estimator = m_estimator;
     int rc = rtw_render(m_ctx, &p, m_hostBuffer.data(), &m_stats);
     if (rc != RTW_OK) die(m_ctx, "rtw_render", rc);
+    if (m_denoiseIterations > 0) {
+        // Director.cpp:986-997: the denoiser pass closes the frame. The reference feeds its LDR model the display-encoded
+        // image (raygen.cu:151-155 writes sqrt(colour)); the stand-in filters the same encoding, clamped to [0, 1], and
+        // the buffer goes back to linear for the writers.
+        std::vector<float> enc(m_hostBuffer.size()), filtered(m_hostBuffer.size());
+        for (size_t i = 0; i < enc.size(); i++) {
+            float c = m_hostBuffer[i];
+            if ((i & 3) != 3) { c = !(c == c) || c < 0.f ? 0.f : (c > 1.f ? 1.f : c); c = std::sqrt(c); }
+            enc[i] = c;
+        }
+        rc = rtw_denoise(m_ctx, enc.data(), filtered.data(), m_Nx, m_Ny, m_denoiseIterations, m_denoiseSigma);
+        if (rc != RTW_OK) die(m_ctx, "rtw_denoise", rc);
+        for (size_t i = 0; i < enc.size(); i++) m_hostBuffer[i] = (i & 3) != 3 ? filtered[i] * filtered[i] : filtered[i];
+    }
     if (_verbose) {
         const double s = m_stats.seconds > 0 ? m_stats.seconds : 1e-9;
         std::cerr << "INFO: " << m_stats.samples << " samples, " << m_stats.segments << " segments, " << m_stats.shadow_rays

@@ -31,6 +31,9 @@ public:
     void setRngKind(int kind) { m_rngKind = kind; }
     void setDevice(int device) { m_device = device; }
     void setEstimator(int estimator) { m_estimator = estimator; }  // rtw_estimator
+    // the reference's renderFrame ends with the OptiX AI denoiser (Director.cpp:986-997); iterations > 0 runs the
+    // a-trous stand-in (rtw_denoise) on the frame instead
+    void setDenoise(int iterations, float sigma) { m_denoiseIterations = iterations; m_denoiseSigma = sigma; }
     const rtw_stats& stats() const { return m_stats; }
     const std::vector<float>& hostBuffer() const { return m_hostBuffer; }  // linear RGBA, row 0 = bottom row
 
@@ -43,6 +46,8 @@ private:
     int m_rngKind = RTW_RNG_PHILOX;
     int m_device = 0;
     int m_estimator = RTW_EST_REFERENCE;
+    int m_denoiseIterations = 0;
+    float m_denoiseSigma = 0.5f;
     rtw_ctx* m_ctx = nullptr;
     rtwhost::ioScene m_scene;
     std::vector<float> m_hostBuffer;

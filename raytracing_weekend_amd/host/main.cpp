@@ -57,6 +57,7 @@ int main(int argc, char* argv[]) {
     -d N           Maximum path depth (reference: 20)
     -seed N        RNG seed
     -rng K         philox (default) or lcg (the reference's tea+lcg generator)
+    -denoise N     N passes (1..8) of the a-trous filter that stands in for the reference's AI denoiser (default: off)
     -est K         reference (default: the reference's estimator, quirks included), corrected, or brute
                    (corrected without light sampling)
     -gpu N         Device ordinal
@@ -102,6 +103,7 @@ int main(int argc, char* argv[]) {
     director.setSeed(seed);
     director.setRngKind(rng);
     director.setEstimator(estimator);
+    if (intOption(cl_input, "-denoise", "denoise passes", x)) director.setDenoise(clampWarn("Denoise passes", x, 0, 8), 0.5f);
 
     auto start = std::chrono::system_clock::now();
     director.init(Nx, Ny, Ns);

@@ -322,3 +322,18 @@ def corrupted_scenes(w=24, h=16):
         setattr(h2, field, value)
         out.append((name, bytes(h2) + blob[C.sizeof(abi.SceneHeader):]))
     return out
+
+
+def denoise(img, iterations=5, sigma=0.5):
+    """CPU restatement of rtw_denoise."""
+    import ctypes as C
+    import numpy as np
+    lib = load()
+    lib.rtwo_denoise.restype = C.c_int
+    lib.rtwo_denoise.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float]
+    src = np.ascontiguousarray(img, dtype=np.float32)
+    out = np.empty_like(src)
+    rc = lib.rtwo_denoise(src.ctypes.data, out.ctypes.data, src.shape[1], src.shape[0], iterations, sigma)
+    if rc:
+        raise RuntimeError(f"rtwo_denoise: {rc}")
+    return out

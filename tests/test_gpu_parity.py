@@ -267,6 +267,28 @@ def test_corrected_estimators_agree_with_each_other(gpu):
     assert abs(m_ref - m_brute) / m_brute > 0.05
 
 
+def test_denoise_matches_oracle(gpu):
+    """rtw_denoise (the stand-in for the reference's AI denoiser stage) against its CPU restatement: bit-exact, on a
+    noisy low-sample render and on ragged sizes; argument errors are reported."""
+    w, h = 120, 72
+    gpu.upload_scene(abi.build_scene(0, w, h))
+    img, _ = gpu.render(abi.make_params(w, h, 4, 20))
+    for it, sigma in ((1, 0.5), (5, 0.4), (8, 2.0)):
+        assert np.array_equal(gpu.denoise(img, it, sigma), oracle.denoise(img, it, sigma))
+    small = np.random.RandomState(1).rand(3, 5, 4).astype(np.float32)
+    assert np.array_equal(gpu.denoise(small, 4, 0.2), oracle.denoise(small, 4, 0.2))
+    ref, _ = oracle.render(abi.build_scene(0, w, h), abi.make_params(w, h, 256, 20), threads=16)
+    # on the display-encoded image (what the reference's LDR denoiser sees) the filter brings a 4-spp frame closer to
+    # the 256-spp one
+    enc = lambda a: np.concatenate([np.sqrt(np.clip(a[..., :3], 0, 1)), a[..., 3:]], axis=-1).astype(np.float32)
+    rm = lambda a: float(np.sqrt(np.mean((a[..., :3] - enc(ref)[..., :3]) ** 2)))
+    assert rm(gpu.denoise(enc(img), 4, 0.5)) < 0.9 * rm(enc(img))
+    with pytest.raises(RuntimeError):
+        gpu.denoise(img, 0, 0.5)
+    with pytest.raises(RuntimeError):
+        gpu.denoise(img, 3, -1.0)
+
+
 def test_edge_cases(gpu):
     blob = abi.build_scene(0, 8, 8)
     gpu.upload_scene(blob)

@@ -246,3 +246,29 @@ def test_corrected_estimators_on_the_oracle():
     for bad in (-1, 3):
         p = abi.make_params(w, h, 1, 2, estimator=bad)
         assert lib.rtwo_render(blob, len(blob), C.byref(p), out.ctypes.data, C.byref(st), 1) == -1
+
+
+def test_denoise_stand_in_on_the_oracle():
+    """The a-trous filter (rtw_denoise / rtwo_denoise): constants pass through, noise shrinks, edges survive."""
+    rs = np.random.RandomState(3)
+    flat = np.full((20, 24, 4), 0.25, np.float32)
+    assert np.array_equal(oracle.denoise(flat, 3, 0.5), flat)
+    clean = np.zeros((48, 64, 4), np.float32)
+    clean[:, :32, :3] = 0.2
+    clean[:, 32:, :3] = 0.9
+    clean[..., 3] = 1.0
+    noisy = clean.copy()
+    noisy[..., :3] += rs.normal(0, 0.05, (48, 64, 3)).astype(np.float32)
+    den = oracle.denoise(noisy, 5, 0.3)
+    err = lambda a: float(np.sqrt(np.mean((a[..., :3] - clean[..., :3]) ** 2)))
+    assert err(den) < 0.35 * err(noisy)
+    assert abs(den[24, 28, 0] - 0.2) < 0.03 and abs(den[24, 36, 0] - 0.9) < 0.03   # the edge is kept
+    assert np.array_equal(den[..., 3], noisy[..., 3])
+    import ctypes as C2
+    lib = oracle.load()
+    lib.rtwo_denoise.restype = C2.c_int
+    lib.rtwo_denoise.argtypes = [C2.c_void_p, C2.c_void_p, C2.c_int, C2.c_int, C2.c_int, C2.c_float]
+    out = np.empty_like(noisy)
+    assert lib.rtwo_denoise(noisy.ctypes.data, out.ctypes.data, 64, 48, 0, 0.3) == -1
+    assert lib.rtwo_denoise(noisy.ctypes.data, out.ctypes.data, 64, 48, 3, 0.0) == -1
+    assert lib.rtwo_denoise(noisy.ctypes.data, noisy.ctypes.data, 64, 48, 3, 0.3) == -1
