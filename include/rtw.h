@@ -185,7 +185,8 @@ typedef struct rtw_scene_header {
  * while emitter hits are counted in full (Q3), the pdf rectangle of the scene instead of the chosen light's own (Q12,
  * and every light but the first), an un-normalised incoming direction in the metal reflection (Q5).
  * RTW_EST_CORRECTED fixes those: cosine-weighted scattering, each listed light sampled over its own parallelogram with
- * the plain area-measure estimator, emitter hits of listed lights counted only where no light sample stood in for them.
+ * the plain area-measure estimator, emitter hits of listed lights counted only where no light sample stood in for them,
+ * media that scatter only inside their extent (Q9), rays started 1e-3 (not 1e-6) away from the hit point.
  * RTW_EST_CORRECTED_NO_NEE is the same integrand estimated without light sampling (every emitter hit counts): slow to
  * converge, but an independent check - both converge to the same image. */
 typedef enum rtw_estimator {

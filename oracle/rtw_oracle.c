@@ -234,6 +234,7 @@ typedef struct {
      * and which primitives those are */
     rtw_light* clights;
     uint8_t* listed;
+    int bounded_media; /* corrected estimators: a medium scatters only inside its extent (the reference does not test it, Q9) */
 } scene_t;
 
 static int scene_open(scene_t* s, const void* blob, size_t bytes) {
@@ -251,6 +252,7 @@ static int scene_open(scene_t* s, const void* blob, size_t bytes) {
     s->h = h;
     s->clights = NULL;
     s->listed = NULL;
+    s->bounded_media = 0;
     s->prims = (const rtw_prim*)(b + h->off_prims);
     s->xforms = (const rtw_xform*)(b + h->off_xforms);
     s->mats = (const rtw_material*)(b + h->off_materials);
@@ -478,6 +480,7 @@ static int prim_intersect(const scene_t* sc, int pi, v3 o, v3 d, float tmin, flo
         float hit_distance = -(1.0f / pr->p[6]) * rtwo_logf(rng_randf(g));
         float t = h1 + hit_distance / len;
         if (!(t >= tmin && t < tmax_cur)) return 0; /* optixReportIntersection interval test */
+        if (sc->bounded_media && !(t < h2)) return 0; /* corrected: the free flight left the medium */
         scratch->o_obj = oo; scratch->d_obj = dd;
         *t_out = t;
         return 1;
@@ -496,6 +499,7 @@ static int prim_intersect(const scene_t* sc, int pi, v3 o, v3 d, float tmin, flo
         float hit_distance = -(1.0f / pr->p[4]) * rtwo_logf(rng_next(g, 1));
         float t = h1 + hit_distance / len;
         if (!(t >= tmin && t < tmax_cur)) return 0;
+        if (sc->bounded_media && !(t < h2)) return 0;
         scratch->o_obj = oo; scratch->d_obj = dd;
         *t_out = t;
         return 1;
@@ -1084,6 +1088,7 @@ int rtwo_render(const void* blob, size_t bytes, const rtw_params* P, float* rgba
     if (rc) return rc;
     if (!rgba_out) return RTW_ERR_INVALID_ARG;
     if (P->estimator == RTW_EST_CORRECTED && (rc = corrected_lights_build(&sc)) != RTW_OK) { corrected_lights_free(&sc); return rc; }
+    sc.bounded_media = P->estimator != RTW_EST_REFERENCE;
     int rows = local_rows_of(P);
     if (threads < 1) threads = 1;
     if (threads > rows) threads = rows > 0 ? rows : 1;
@@ -1139,6 +1144,7 @@ int rtwo_trace_pixel(const void* blob, size_t bytes, const rtw_params* P, int px
     if (rc) return rc;
     counters_t cn = {0, 0};
     if (P->estimator == RTW_EST_CORRECTED && (rc = corrected_lights_build(&sc)) != RTW_OK) { corrected_lights_free(&sc); return rc; }
+    sc.bounded_media = P->estimator != RTW_EST_REFERENCE;
     v3 L = trace_path(&sc, P, px, py, sample, &cn);
     corrected_lights_free(&sc);
     rgb_out[0] = L.x; rgb_out[1] = L.y; rgb_out[2] = L.z;

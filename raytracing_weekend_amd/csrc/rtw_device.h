@@ -497,7 +497,9 @@ RTW_DEV void object_ray(const DScene& sc, const rtw_prim& pr, v3 o, v3 d, float 
 // inv = (1/dd.x, 1/dd.y, 1/dd.z) by IEEE division: the caller computes it once per object-space ray and
 // reuses it for every rectangle / box under the same transform (same bits as dividing per primitive).
 template <class RNG>
-RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, v3 inv, float tmin, float tmax_cur, float gather_time, RNG& g, float& t_out) {
+// bounded (corrected estimators): a medium only scatters inside its extent; the reference does not test that (Q9)
+RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, v3 inv, float tmin, float tmax_cur, float gather_time, RNG& g, float& t_out,
+                       bool bounded = false) {
     switch (pr.type) {
     case RTW_PRIM_SPHERE:
         return sphere_roots(oo, dd, ld3(&pr.p[0]), pr.p[3], tmin, tmax_cur, t_out);
@@ -536,6 +538,7 @@ RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, v3 inv, float tmin, flo
         float hit_distance = -(1.0f / pr.p[6]) * log_spec(g.randf1());
         float t = h1 + hit_distance / len;
         if (!(t >= tmin && t < tmax_cur)) return false;
+        if (bounded && !(t < h2)) return false;
         t_out = t;
         return true;
     }
@@ -553,6 +556,7 @@ RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, v3 inv, float tmin, flo
         float hit_distance = -(1.0f / pr.p[4]) * log_spec(g.next1());
         float t = h1 + hit_distance / len;
         if (!(t >= tmin && t < tmax_cur)) return false;
+        if (bounded && !(t < h2)) return false;
         t_out = t;
         return true;
     }
@@ -635,7 +639,7 @@ RTW_DEV bool volume_pass(const DScene& sc, v3 o, v3 d, float tmin, float ray_tim
         v3 po, pd, mt;
         object_ray(sc, pr, o, d, ray_time, po, pd, mt);
         float t;
-        if (prim_test(pr, po, pd, recip3(pd), tmin, best_t, gather_time, g, t)) {
+        if (prim_test(pr, po, pd, recip3(pd), tmin, best_t, gather_time, g, t, sc.estimator != 0)) {
             best_t = t;
             best_prim = pi;
             hit = true;
