@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--check", action="store_true", help="rank 0 re-renders the full frame alone and asserts the gathered image is identical")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this pool
     import torch
     import torch.distributed as dist
     from raytracing_weekend_amd import abi
