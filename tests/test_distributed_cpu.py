@@ -22,7 +22,7 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_path, h, w, interleaved):
+def _worker(rank, world, port, out_path, h, w, interleaved, scene=0, estimator=0):
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -32,15 +32,15 @@ def _worker(rank, world, port, out_path, h, w, interleaved):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    blob = abi.build_scene(0, w, h)
+    blob = abi.build_scene(scene, w, h)
     if interleaved:
         row0, row1, stride, n = interleaved_shard(h, world, rank)
         max_rows = max(interleaved_shard(h, world, g)[3] for g in range(world))
-        p = abi.make_params(w, h, 3, 5, row0=row0, row1=row1, row_stride=stride)
+        p = abi.make_params(w, h, 3, 5, row0=row0, row1=row1, row_stride=stride, estimator=estimator)
     else:
         rows = partition_rows(h, world)
         max_rows = max(rows[g + 1] - rows[g] for g in range(world))
-        p = abi.make_params(w, h, 3, 5, row0=rows[rank], row1=rows[rank + 1])
+        p = abi.make_params(w, h, 3, 5, row0=rows[rank], row1=rows[rank + 1], estimator=estimator)
     img, _ = oracle.render(blob, p, threads=2)
     tile = torch.zeros((max_rows, w, 4), dtype=torch.float32)
     tile[: img.shape[0]] = torch.from_numpy(img)
@@ -51,8 +51,9 @@ def _worker(rank, world, port, out_path, h, w, interleaved):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,interleaved", [(2, 37, True), (3, 20, True), (2, 21, False)])
-def test_row_shard_gather_matches_single_process(tmp_path, world, h, interleaved):
+@pytest.mark.parametrize("world,h,interleaved,scene,estimator", [(2, 37, True, 0, 0), (3, 20, True, 0, 0), (2, 21, False, 0, 0),
+                                                                  (2, 19, True, 4, 1)])  # textures, tree, media, corrected estimator
+def test_row_shard_gather_matches_single_process(tmp_path, world, h, interleaved, scene, estimator):
     w = 48
     for p in (ROOT, os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -60,9 +61,9 @@ def test_row_shard_gather_matches_single_process(tmp_path, world, h, interleaved
     import oracle
     from raytracing_weekend_amd import abi
     out = str(tmp_path / "full.npy")
-    mp.spawn(_worker, args=(world, _free_port(), out, h, w, interleaved), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), out, h, w, interleaved, scene, estimator), nprocs=world, join=True)
     got = np.load(out)
-    want, _ = oracle.render(abi.build_scene(0, w, h), abi.make_params(w, h, 3, 5), threads=2)
+    want, _ = oracle.render(abi.build_scene(scene, w, h), abi.make_params(w, h, 3, 5, estimator=estimator), threads=2)
     assert got.shape == (h, w, 4)
     assert np.array_equal(got, want)
 
