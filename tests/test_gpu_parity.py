@@ -205,7 +205,8 @@ def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
              (oracle.textured_cornell(64, 48, extra=30), 64, 48, 6, 20)]
     knobs = [{}, {"RTW_LANES": "1"}, {"RTW_LANES": "3", "RTW_POOL_PATHS": "20000"}, {"RTW_FUSED": "1"}, {"RTW_SPLIT_MEDIA": "0"},
              {"RTW_TAIL_START": "2"}, {"RTW_TAIL_START": "40", "RTW_GRID_MULT": "1"}, {"RTW_LDS_KB": "0"},
-             {"RTW_LDS_KB": "48", "RTW_BRUTE_MAX": "0"}, {"RTW_POOL_PATHS": "4096", "RTW_GRID_MULT": "3"}]
+             {"RTW_LDS_KB": "48", "RTW_BRUTE_MAX": "0"}, {"RTW_POOL_PATHS": "4096", "RTW_GRID_MULT": "3"},
+             {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "0"}, {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "30"}]
     names = sorted({k for kn in knobs for k in kn})
     for blob, w, h, spp, depth in cases:
         ref = None
