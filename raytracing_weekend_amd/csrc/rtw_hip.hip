@@ -688,7 +688,10 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         for (size_t s0 = 0, Sb = 0; s0 < (size_t)P->spp; s0 += Sb, bi++) {
             rtw_ctx::Lane& L = c->lane[bi % (size_t)n_lanes];
             hipStream_t ls = L.st;
-            Sb = std::min((stagger_pct > 0 && bi == 1 && S > 1) ? std::max<size_t>(1, S * (size_t)stagger_pct / 100) : S, (size_t)P->spp - s0);
+            size_t want = S;
+            if (stagger_pct > 0 && bi > 0 && bi < (size_t)n_lanes && S > 1)  // lane k starts k/n_lanes of a batch late (at 50 %)
+                want = std::max<size_t>(1, S - S * bi * (size_t)stagger_pct * 2 / (100 * (size_t)n_lanes));
+            Sb = std::min(want, (size_t)P->spp - s0);
             const size_t paths = npix * Sb;
             const uint32_t regions = grid_for(paths);
             const size_t region_cap = cap_for(paths);
