@@ -240,7 +240,9 @@ int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids);
 int rtw_upload_scene(rtw_ctx* ctx, const void* scene_blob, size_t bytes);
 
 /* Replaces optixLaunch + the D2H copy (Director.cpp:982-984, 999-1000).
- * rgba_out: host, (row1-row0)*width float4, LINEAR mean radiance, alpha 1; row r of the tile is image row row0+r. */
+ * rgba_out: host, rows*width float4 (rows = the rows of [row0,row1) the shard owns: all of them, or every
+ * row_stride-th), LINEAR mean radiance of samples [sample_offset, sample_offset+spp), alpha 1; row r of the output is
+ * image row row0 + r*max(row_stride,1); image row 0 is the bottom row, like the reference's frame buffer. */
 int rtw_render(rtw_ctx* ctx, const rtw_params* params, float* rgba_out, rtw_stats* stats);
 
 /* Same render, result left in device memory (d_rgba: device pointer, same layout), launched on
@@ -251,6 +253,8 @@ int rtw_render_device(rtw_ctx* ctx, const rtw_params* params, void* d_rgba, void
 /* Replaces Director::destroy (Director.cpp:66-104). */
 int rtw_destroy(rtw_ctx* ctx);
 
+/* Message of the last failing call on this context (what OPTIX_CHECK / CUDA_CHECK would have thrown,
+ * sutil/Exception.h); valid until the next call on the context. */
 const char* rtw_last_error(rtw_ctx* ctx);
 
 /* Stand-in for the reference's output stage, the OptiX AI denoiser (Director::initDenoiser, Director.cpp:887-949,
