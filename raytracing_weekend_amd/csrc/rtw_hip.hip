@@ -167,6 +167,7 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_SPLIT_MEDIA=0  scenes with media: every bounce through k_bounce (default: split pipeline, volumes tested in the shading kernels)
 //   RTW_BRUTE_MAX   largest primitive count walked with the scalar-cache brute lists (default 24; 0 forces the BVH)
 //   RTW_LDS_KB      dynamic LDS per workgroup for traversal stacks + staged tree nodes (default 16)
+//   RTW_TAIL_GROUP  bounces per launch of the first tail group (default 2; groups grow by half every second launch)
 //   RTW_STAGGER     size of the second lane's first batch in percent of a full batch (default 50; 0 = no offset)
 struct Tuning {
     size_t pool_paths = (size_t)1 << 28;
@@ -178,6 +179,7 @@ struct Tuning {
     int brute_max = kBruteMaxPrims;
     size_t lds_kb = 16;
     int stagger_pct = 50;
+    int tail_group = 2;
 };
 Tuning read_tuning() {
     Tuning t;
@@ -196,6 +198,7 @@ Tuning read_tuning() {
     if (geti("RTW_SPLIT_MEDIA", v)) t.split_media = v != 0;
     if (geti("RTW_BRUTE_MAX", v)) t.brute_max = (int)v;
     if (geti("RTW_LDS_KB", v)) t.lds_kb = (size_t)std::max<long long>(0, v);
+    if (geti("RTW_TAIL_GROUP", v)) t.tail_group = (int)std::max<long long>(1, std::min<long long>(64, v));
     if (geti("RTW_STAGGER", v)) t.stagger_pct = (int)std::max<long long>(0, std::min<long long>(99, v));
     return t;
 }
@@ -611,7 +614,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         // pipeline longer (scene 4: +18 % at 24 vs 6; scenes 1, 2: flat)
         const int tail_start = tune.tail_start > 0 ? tune.tail_start : (c->sc.use_bvh ? 20 : 6);
         const bool split = !tune.fused && (c->sc.n_vol == 0 || tune.split_media);
-        int d = 0, grp = 2, rep = 0;
+        int d = 0, grp = tune.tail_group, rep = 0;
         while (d < P->max_depth) {
             if (d < tail_start) {
                 if (split) {
