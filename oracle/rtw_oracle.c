@@ -12,6 +12,8 @@
  *     Philox4x32-10 is pinned by the Random123 known-answer vectors.
  *   - Everything else (pixels) is PARITY UNPINNED against OptiX: the checker is this restatement,
  *     function by function, each citing the reference file:line it follows.
+ *   - rtw_params.estimator != 0 (corrected estimators) and rtwo_denoise are this build's own definitions, not the
+ *     reference's: there the file is the CPU twin of the HIP code, nothing more.
  *
  * Arithmetic contract shared with the HIP kernels (DESIGN.md "arithmetic spec"): fp32 only,
  * no compiler contraction (-ffp-contract=off), fused multiply-adds only where fmaf() is written,
@@ -537,7 +539,7 @@ static void traverse(const scene_t* sc, v3 o, v3 d, float tmin, float tmax, floa
 }
 
 /* Attributes of the committed hit: world point, shading normal (what the IS programs pass through
- * optixReportIntersection registers 0..7). u,v are not produced: only constant/null textures are in scope.
+ * optixReportIntersection registers 0..7), and the texture coordinates u, v of the same programs.
  * The world point is the world ray evaluated at t — the same real point as the reference's
  * optixTransformPointFromObjectToWorldSpace(o_obj + t*d_obj), without the round trip through object space. */
 /* geometry/sphere.cu:24-30 get_sphere_uv, applied to the (unnormalised) shading normal */

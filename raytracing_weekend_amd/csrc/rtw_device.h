@@ -752,7 +752,7 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
 // candidate lists: the two rays share their origin, so each group's object-space origin and each record's
 // scalar load and plane offset (k - o) are computed once. Per ray the arithmetic is exactly that of
 // traverse<>: same operations, same order, same tie rule (the images stay bit-identical).
-// Only for scenes without volume or moving-sphere candidates (n_vol == 0 && n_generic == 0).
+// Surfaces only (volumes are never in these lists); not for scenes with moving spheres (n_generic == 0).
 RTW_DEV void traverse_dual_brute(const DScene& sc, const v3 o, const v3 dr, const v3 ds, const bool do_r, const bool do_s,
                                  const float smin, const float smax, float& best_t, int& best_prim, bool& occluded) {
     const float rmin = sc.ray_tmin;
