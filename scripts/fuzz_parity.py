@@ -1,0 +1,34 @@
+"""usage: fuzz_parity.py [n] [first_seed] — GPU vs oracle on n synthetic scenes (tests/oracle.py random_scene) with random
+image sizes, depths, sample counts, generators and estimators. Prints every mismatch and a summary; exit code 1 on any."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from raytracing_weekend_amd import abi
+import oracle
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
+r = abi.Renderer(0)
+bad = 0
+for seed in range(first, first + n):
+    rs = np.random.RandomState(seed)
+    kw = dict(n_prims=int(rs.choice([4, 9, 16, 24, 25, 40, 90, 200])), volumes=bool(rs.randint(2)), motion=bool(rs.randint(2)),
+              n_lights=int(rs.randint(0, 4)), sky=bool(rs.randint(2)), textured=bool(rs.randint(3) == 0))
+    w, h = int(rs.randint(9, 120)), int(rs.randint(9, 90))
+    blob = oracle.random_scene(seed, w, h, **kw)
+    p = abi.make_params(w, h, int(rs.randint(1, 9)), int(rs.choice([1, 2, 5, 12, 50])), rng_kind=int(rs.randint(2)),
+                        seed=int(rs.randint(1, 1 << 31)), estimator=int(rs.choice([0, 0, 1, 2])), sample_offset=int(rs.choice([0, 0, 7])))
+    r.upload_scene(blob)
+    img, st = r.render(p)
+    ref, st_ref = oracle.render(blob, p, threads=16)
+    ok = np.array_equal(img, ref) and st.segments == st_ref.segments and st.shadow_rays == st_ref.shadow_rays
+    if not ok:
+        bad += 1
+        d = np.argwhere(np.any(img != ref, axis=-1))
+        print("MISMATCH seed", seed, kw, (w, h), dict(spp=p.spp, depth=p.max_depth, rng=p.rng_kind, est=p.estimator),
+              "pixels", len(d), "first", d[:3].tolist(), "seg", st.segments, st_ref.segments, flush=True)
+    if (seed - first) % 50 == 49:
+        print("checked", seed - first + 1, "mismatches", bad, flush=True)
+print("done:", n, "scenes,", bad, "mismatches")
+sys.exit(1 if bad else 0)

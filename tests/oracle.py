@@ -90,7 +90,7 @@ def cluttered_cornell(w, h, n_extra=40, seed=7, scene=0):
     return abi.assemble_scene(parts)
 
 
-def random_scene(seed, w, h, n_prims=30, volumes=False, motion=False, n_lights=1, sky=False):
+def random_scene(seed, w, h, n_prims=30, volumes=False, motion=False, n_lights=1, sky=False, textured=False):
     """A synthetic scene for fuzzing GPU-vs-oracle parity: every primitive kind under random rigid transforms, every
     material kind, 0..n rectangle lights in the light list, optional sky light / volumes / moving spheres. The camera,
     the image plane and the pdf record come from the Cornell box header (the content sits in its 0..555 cube)."""
@@ -180,7 +180,18 @@ def random_scene(seed, w, h, n_prims=30, volumes=False, motion=False, n_lights=1
             add(abi.PRIM_VOLUME_BOX, (lo[0], lo[1], lo[2], lo[0] + rs.uniform(60, 180), lo[1] + rs.uniform(60, 180), lo[2] + rs.uniform(60, 180), rs.uniform(0.002, 0.02)), i_iso, xf)
         elif volumes:
             add(abi.PRIM_VOLUME_SPHERE, (c[0], c[1], c[2], rs.uniform(40, 110), rs.uniform(0.002, 0.02)), i_iso, xf)
-    parts.update(header=hdr, prims=prims, xforms=xforms, materials=materials, textures=textures, lights=lights)
+    texdata = b""
+    if textured:  # the three Lambertian materials and the metal get noise / checker / image / checker-of-those textures
+        texdata = perlin_tables(seed) + test_image(seed=seed)
+        t_noise = abi.Texture(type=abi.TEX_NOISE, scale=float(rs.choice([0.02, 0.1, 1.0])), data=0)
+        t_img = abi.Texture(type=abi.TEX_IMAGE, data=1536)
+        textures.extend([t_noise, t_img])
+        i_noise, i_img = len(textures) - 2, len(textures) - 1
+        textures.append(abi.Texture(type=abi.TEX_CHECKER, odd=0, even=i_img))
+        textures.append(abi.Texture(type=abi.TEX_CHECKER, odd=i_noise, even=1))
+        for m, t in zip(range(4), (i_noise, i_img, len(textures) - 2, len(textures) - 1)):
+            materials[m].texture = t
+    parts.update(header=hdr, prims=prims, xforms=xforms, materials=materials, textures=textures, lights=lights, texdata=texdata)
     return abi.assemble_scene(parts)
 
 
