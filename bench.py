@@ -102,7 +102,10 @@ def main():
     host_gather = world > 1 and args.backend != "nccl"
     gdev = torch.device("cpu") if host_gather else dev
     gathered = [torch.empty((max_rows, WIDTH, 4), dtype=torch.float32, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
-    stream = torch.cuda.current_stream(dev).cuda_stream
+    # a stream of our own: handle 0 (torch's default stream) would select the library's private stream (include/rtw.h)
+    tstream = torch.cuda.Stream(dev)
+    tstream.wait_stream(torch.cuda.current_stream(dev))
+    stream = tstream.cuda_stream
 
     def step():
         st = r.render_device(params, tile.data_ptr(), stream)
@@ -151,11 +154,12 @@ def main():
         # algorithmic bytes are 128 B per radiance segment it processed (64 B of SoA path state read
         # and written once per segment; for k_trace, per ray pair traced); its time is measured live with HIP
         # events recorded on the launch stream around every launch inside rtw_render_device.
-        names = ("k_first", "k_shade", "k_trace", "k_bounce")
-        k_s = [sum(s.kernel_seconds[i] for s in stats) for i in range(4)]
-        k_n = [sum(s.kernel_launches[i] for s in stats) for i in range(4)]
-        k_seg = [sum(s.kernel_segments[i] for s in stats) for i in range(4)]
-        dom = max(range(4), key=lambda i: k_s[i])
+        names = abi.Stats.KERNELS
+        NK = len(names)
+        k_s = [sum(s.kernel_seconds[i] for s in stats) for i in range(NK)]
+        k_n = [sum(s.kernel_launches[i] for s in stats) for i in range(NK)]
+        k_seg = [sum(s.kernel_segments[i] for s in stats) for i in range(NK)]
+        dom = max(range(NK), key=lambda i: k_s[i])
         seg0 = float(sum(s.segments for s in stats))
         b_s, b_n, r_s = (float(x) for x in kt.tolist())
         dom_units = float(k_seg[dom]) if dom != 2 else float(k_seg[dom]) / 2.0
@@ -199,7 +203,7 @@ def main():
                                         "seconds": round(b_s, 4), "launches": int(b_n),
                                         "note": "128 B x all segments / device time of the render calls (all four kernels, both lanes)"},
                          "per_kernel": {names[i]: {"seconds": round(k_s[i], 4), "launches": int(k_n[i]), "units": int(k_seg[i])}
-                                        for i in range(4)},
+                                        for i in range(NK) if k_n[i]},
                          "render_device_seconds_rank0": round(r_s, 4)},
         }
         if world == 1:

@@ -34,8 +34,14 @@
 extern "C" {
 #endif
 
-#define RTW_ABI_VERSION 1
+#define RTW_ABI_VERSION 2   /* entry points and the structs they take (rtw_params, rtw_stats) */
+#define RTW_SCENE_VERSION 1 /* layout of the scene blob (rtw_scene_header.version) */
 #define RTW_SCENE_MAGIC 0x57545221u /* "!RTW" */
+/* Summation order of a pixel's samples (part of the arithmetic contract): the samples of a render call are
+ * summed in ascending order inside aligned blocks of RTW_SUM_BLOCK samples (counted from sample_offset), and the block
+ * sums are added in ascending order; the mean is that sum divided by spp. The reference renders one sample per launch
+ * (raygen.cu:123-159) and so defines no order; blocks let a lane own a pixel's block in registers. */
+#define RTW_SUM_BLOCK 64
 
 typedef enum rtw_status {
     RTW_OK = 0,
@@ -169,7 +175,7 @@ typedef struct rtw_camera {
  * (all offsets relative to the start of the header, 16-byte aligned). */
 typedef struct rtw_scene_header {
     uint32_t magic;   /* RTW_SCENE_MAGIC */
-    uint32_t version; /* RTW_ABI_VERSION */
+    uint32_t version; /* RTW_SCENE_VERSION */
     uint32_t total_bytes;
     uint32_t n_prims, n_xforms, n_materials, n_textures, n_lights;
     uint32_t off_prims, off_xforms, off_materials, off_textures, off_lights;
@@ -211,7 +217,7 @@ typedef struct rtw_params {
 } rtw_params;
 
 /* kernels of the wavefront loop, index into the per-kernel arrays of rtw_stats */
-enum { RTW_K_FIRST = 0, RTW_K_SHADE = 1, RTW_K_TRACE = 2, RTW_K_BOUNCE = 3, RTW_K_COUNT = 4 };
+enum { RTW_K_FIRST = 0, RTW_K_SHADE = 1, RTW_K_TRACE = 2, RTW_K_BOUNCE = 3, RTW_K_PATH = 4, RTW_K_COUNT = 5 };
 
 typedef struct rtw_stats {
     uint64_t samples;           /* camera paths started                                              */
@@ -232,7 +238,13 @@ typedef struct rtw_ctx rtw_ctx;
 
 int rtw_abi_version(void);
 
-/* Replaces Director::initContext (Director.cpp:106-122). One context per GPU. */
+/* Replaces Director::initContext (Director.cpp:106-122).
+ * n_devices == 1: one context on device_ids[0] (NULL: device 0).
+ * n_devices  > 1: a group. rtw_upload_scene copies the scene to every device; rtw_render / rtw_render_device split the
+ * rows of the call into n_devices interleaved shards (shard g: every n_devices-th row of the call's rows, starting at its
+ * g-th), render shard g on device_ids[g] from its own host thread, gather the float4 shards on device_ids[0] with one
+ * hipMemcpyPeerAsync each (xGMI) and interleave them there: the caller sees one frame, bit-identical to the
+ * single-device render. Entries of device_ids may repeat (two shards on one GPU). The caller stays single-threaded. */
 int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids);
 
 /* Replaces createSBT + initLaunchParams + the per-primitive optixAccelBuild calls
@@ -245,8 +257,12 @@ int rtw_upload_scene(rtw_ctx* ctx, const void* scene_blob, size_t bytes);
  * image row row0 + r*max(row_stride,1); image row 0 is the bottom row, like the reference's frame buffer. */
 int rtw_render(rtw_ctx* ctx, const rtw_params* params, float* rgba_out, rtw_stats* stats);
 
-/* Same render, result left in device memory (d_rgba: device pointer, same layout), launched on
- * hip_stream (a hipStream_t passed as void*, NULL = the context's own stream). Returns when done. */
+/* Same render, result left in device memory (d_rgba: device pointer on device_ids[0], same layout). The work is ordered
+ * on hip_stream (a hipStream_t passed as void*): the render starts after what that stream holds and the final frame is
+ * written on it. NULL (which is also HIP's legacy default stream handle) selects the context's own non-blocking stream,
+ * which is NOT ordered with the default stream: pass a stream of your own (or hipStreamLegacy / hipStreamPerThread) when
+ * d_rgba has pending work. Returns when done. rtw_stats.kernel_seconds is filled from HIP events recorded on the launch
+ * streams around every kernel (only when stats != NULL; RTW_KERNEL_TIMING=0 turns the events off). */
 int rtw_render_device(rtw_ctx* ctx, const rtw_params* params, void* d_rgba, void* hip_stream,
                       rtw_stats* stats);
 

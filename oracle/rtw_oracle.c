@@ -242,7 +242,7 @@ typedef struct {
 static int scene_open(scene_t* s, const void* blob, size_t bytes) {
     if (!blob || bytes < sizeof(rtw_scene_header)) return RTW_ERR_BAD_SCENE;
     const rtw_scene_header* h = (const rtw_scene_header*)blob;
-    if (h->magic != RTW_SCENE_MAGIC || h->version != RTW_ABI_VERSION || h->total_bytes > bytes)
+    if (h->magic != RTW_SCENE_MAGIC || h->version != RTW_SCENE_VERSION || h->total_bytes > bytes)
         return RTW_ERR_BAD_SCENE;
     const char* b = (const char*)blob;
     if ((size_t)h->off_prims + (size_t)h->n_prims * sizeof(rtw_prim) > bytes) return RTW_ERR_BAD_SCENE;
@@ -1047,10 +1047,16 @@ static void render_rows(const scene_t* sc, const rtw_params* P, int l0, int l1, 
     for (int l = l0; l < l1; l++) {
         int y = P->row0 + l * k;
         for (int x = 0; x < W; x++) {
+            /* summation order of include/rtw.h RTW_SUM_BLOCK: in order inside aligned blocks, then the block sums in order */
             v3 sum = V(0.f, 0.f, 0.f);
-            for (int s = 0; s < P->spp; s++) {
-                v3 L = trace_path(sc, P, x, y, P->sample_offset + s, cn);
-                sum = vadd(sum, L);
+            for (int s0 = 0; s0 < P->spp; s0 += RTW_SUM_BLOCK) {
+                v3 bsum = V(0.f, 0.f, 0.f);
+                const int s1 = s0 + RTW_SUM_BLOCK < P->spp ? s0 + RTW_SUM_BLOCK : P->spp;
+                for (int s = s0; s < s1; s++) {
+                    v3 L = trace_path(sc, P, x, y, P->sample_offset + s, cn);
+                    bsum = vadd(bsum, L);
+                }
+                sum = vadd(sum, bsum);
             }
             float n = (float)P->spp;
             float* o = out + 4 * ((size_t)l * (size_t)W + (size_t)x);

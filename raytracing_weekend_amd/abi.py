@@ -14,7 +14,8 @@ REPO_DIR = os.path.dirname(PKG_DIR)
 HOST_LIB = os.path.join(PKG_DIR, "host", "librtw_host.so")
 HIP_LIB = os.environ.get("RTW_HIP_LIB") or os.path.join(PKG_DIR, "csrc", "librtw_hip.so")
 
-RTW_ABI_VERSION = 1
+RTW_ABI_VERSION = 2
+RTW_SCENE_VERSION = 1
 RTW_SCENE_MAGIC = 0x57545221
 RTW_RNG_PHILOX = 0
 RTW_RNG_TEA_LCG = 1
@@ -84,9 +85,9 @@ class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("segments", C.c_uint64), ("shadow_rays", C.c_uint64),
                 ("algorithmic_bytes", C.c_uint64), ("bounce_launches", C.c_uint64), ("reserved", C.c_uint64),
                 ("seconds", C.c_double), ("bounce_seconds", C.c_double),
-                ("kernel_seconds", C.c_double * 4), ("kernel_launches", C.c_uint64 * 4), ("kernel_segments", C.c_uint64 * 4)]
+                ("kernel_seconds", C.c_double * 5), ("kernel_launches", C.c_uint64 * 5), ("kernel_segments", C.c_uint64 * 5)]
 
-    KERNELS = ("k_first", "k_shade", "k_trace", "k_bounce")
+    KERNELS = ("k_first", "k_shade", "k_trace", "k_bounce", "k_path")
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
@@ -220,13 +221,15 @@ def local_rows(params):
 
 
 class Renderer:
-    """Thin owner of one rtw_ctx (one GPU)."""
+    """Thin owner of one rtw_ctx: one GPU (device=i) or an in-library group (device=[i, j, ...]: rtw_create with
+    n_devices > 1, one interleaved row shard per entry, gathered on the first device)."""
 
     def __init__(self, device=0):
         self.lib = load_hip()
         self.ctx = C.c_void_p()
-        dev = (C.c_int * 1)(device)
-        rc = self.lib.rtw_create(C.byref(self.ctx), 1, dev)
+        ids = list(device) if isinstance(device, (list, tuple)) else [device]
+        dev = (C.c_int * len(ids))(*ids)
+        rc = self.lib.rtw_create(C.byref(self.ctx), len(ids), dev)
         if rc != 0:
             raise RuntimeError(f"rtw_create failed: {rc}")
 

@@ -218,6 +218,18 @@ inline Bvh build_bvh(const rtw_prim* prims, uint32_t n_prims, const rtw_xform* x
                 if (out.nodes[nd.left_first + c].count == 0) queue.push_back(nd.left_first + c);
         }
     }
+    if (nw == 0) {
+        // The root is a leaf (one or two surfaces: a tree scene made of volumes, or RTW_BRUTE_MAX=0 on a tiny scene). The
+        // device walk always starts at inner record 0, so the leaf becomes the left child of one inner record whose right
+        // child is a box no ray reaches (a point at 3e38: its slab interval never meets [tmin, best_t]).
+        WideNode w{};
+        const Node& rt = out.nodes[0];
+        for (int a = 0; a < 3; a++) { w.lmn[a] = rt.mn[a]; w.lmx[a] = rt.mx[a]; w.rmn[a] = 3.0e38f; w.rmx[a] = 3.0e38f; }
+        w.lref = rt.left_first | (rt.count << 30);
+        w.rref = w.lref;
+        out.wide.push_back(w);
+        return out;
+    }
     out.wide.resize((size_t)nw);
     for (size_t i = 0; i < out.nodes.size(); i++) {
         const Node& nd = out.nodes[i];

@@ -327,6 +327,9 @@ struct BruteRec {
     int32_t pad0, pad1;
 };
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 struct DScene {
     const rtw_prim* __restrict__ prims;
     const rtw_xform* __restrict__ xforms;
@@ -339,8 +342,10 @@ struct DScene {
     const BruteRec* __restrict__ recs;
     const rtw_texture* __restrict__ texs;    // only read for hit records with a non-constant texture
     const uint32_t* __restrict__ texdata;    // noise tables, image texels (rtw.h rtw_texture)
+    const u32x4* __restrict__ walk;          // small scenes: the candidate lists as a stream of items (walk_items), n_walk_words 16-byte words; 0 = none
     int32_t n_prims, n_vol, n_tree, n_lights, sky_light, use_bvh, has_motion, n_groups;
     int32_t n_generic;                       // order[n_vol .. n_vol+n_generic): moving spheres, tested through the generic path
+    int32_t n_walk_words;
     // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks; noise_lds_data: word offset of the
     // noise tables staged in LDS, or -1
     int32_t n_lds_nodes, stack_depth, has_tex, noise_lds_data;
@@ -358,8 +363,6 @@ RTW_DEV bool is_volume(int type) { return type == RTW_PRIM_VOLUME_BOX || type ==
 // address space: a wave-uniform index then becomes an s_load into SGPRs (scalar cache, no VGPRs,
 // no vector-memory latency), a divergent index an ordinary global_load.
 #define RTW_CONST __attribute__((address_space(4)))
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <class T>
 RTW_DEV const RTW_CONST T* as_const(const T* p) { return (const RTW_CONST T*)(uint64_t)p; }
 
@@ -622,10 +625,6 @@ RTW_DEV bool may_hit_scene(const DScene& sc, const v3 o, const v3 d) {
 RTW_DEV bool uses_inv(int type) { return type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_VOLUME_BOX; }
 RTW_DEV v3 recip3(v3 d) { return V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 
-// Closest / any hit (optixTraverse at raygen.cu:41-54 and closehit.cu:27-40).
-// Candidate order (observable only through volume RNG draws and exact ties in t): volume
-// primitives in index order, then everything else with ties resolved to the lowest index.
-// tm: this thread's column of the LDS traversal stack and the block's LDS node cache (trav_mem).
 // The volume primitives' share of a traversal: tested first, in index order, each against the interval the earlier
 // ones left (their intersection programs draw random numbers: geometry/volumeBox.cu:79, volumeSphere.cu:93).
 // Surfaces then only win with a strictly smaller t, so a kernel that holds the generator can run this pass on its
@@ -649,9 +648,153 @@ RTW_DEV bool volume_pass(const DScene& sc, v3 o, v3 d, float tmin, float ray_tim
     return hit;
 }
 
+// Small scenes (the scalar-cache candidate lists): every lane walks the same records, so they arrive as SGPR operands.
+// Per instance transform: one object-space ray, one reciprocal direction, then straight-line tests (rect x / y / z
+// lists, spheres). The record after the one under test is already on its way (the scalar loads return out of order, so a
+// wave cannot keep more than "everything issued so far" apart: one s_waitcnt per record, hidden behind the test).
+// GENERIC = false: the caller knows the scene has no moving spheres (sc.n_generic == 0)
+template <class RNG, bool ANY_HIT, bool SKIP_VOLUMES, bool GENERIC = true>
+RTW_DEV void traverse_brute(const DScene& sc, v3 o, v3 d, float tmin, float tmax, float ray_time, float gather_time, RNG& g,
+                            float& best_t, int& best_prim) {
+    best_t = tmax;
+    best_prim = -1;
+    bool best_is_vol = false;
+    if (!SKIP_VOLUMES) {
+        best_is_vol = volume_pass<RNG, ANY_HIT>(sc, o, d, tmin, ray_time, gather_time, g, best_t, best_prim);
+        if (ANY_HIT && best_is_vol) return;
+    }
+// straight-line candidate test: every comparison is evaluated, the update is one predicated select
+#define RTW_TAKE(HIT_, T_, PI_)                                                                      \
+    {                                                                                                \
+        const bool tie_ = !ANY_HIT && ((T_) == best_t) & ((PI_) < best_prim) & !best_is_vol;         \
+        const bool take_ = (HIT_) & (((T_) < best_t) | tie_);                                        \
+        best_t = take_ ? (T_) : best_t;                                                              \
+        best_prim = take_ ? (PI_) : best_prim;                                                       \
+        best_is_vol = take_ ? false : best_is_vol;                                                   \
+    }
+    int ri = 0;
+    BruteRec R = load_rec(sc, 0);  // (the table always holds one record more than it lists)
+    for (int gi = 0; gi < sc.n_groups; gi++) {
+        const BruteGroup G = load_group(sc, gi);
+        v3 oo = o, dd = d;
+        if (G.xform != 0) { M34 im = load_xf_inv(sc, G.xform); oo = xf_point(im.m, o); dd = xf_vector(im.m, d); }
+        if (G.n_rx + G.n_ry + G.n_rz > 0) {
+            const v3 inv = recip3(dd);
+#define RTW_RECT_LOOP(N_, OK_, IK_, OA_, DA_, OB_, DB_)                                              \
+            for (int i = 0; i < (N_); i++) {                                                         \
+                const BruteRec Rn = load_rec(sc, ++ri);                                              \
+                const float t = (R.e - (OK_)) * (IK_);                                               \
+                const float a = fma_(t, (DA_), (OA_));                                               \
+                const float b = fma_(t, (DB_), (OB_));                                               \
+                const bool hit = (t >= tmin) & (a >= R.a) & (a <= R.b) & (b >= R.c) & (b <= R.d);    \
+                RTW_TAKE(hit, t, R.prim)                                                             \
+                R = Rn;                                                                              \
+            }
+            RTW_RECT_LOOP(G.n_rx, oo.x, inv.x, oo.y, dd.y, oo.z, dd.z)   // shaders/aarectx.cu:8-22
+            RTW_RECT_LOOP(G.n_ry, oo.y, inv.y, oo.x, dd.x, oo.z, dd.z)   // shaders/aarecty.cu:8-22
+            RTW_RECT_LOOP(G.n_rz, oo.z, inv.z, oo.x, dd.x, oo.y, dd.y)   // shaders/aarectz.cu:9-23
+#undef RTW_RECT_LOOP
+        }
+        for (int i = 0; i < G.n_sph; i++) {
+            const BruteRec Rn = load_rec(sc, ++ri);
+            float t = 0.f;
+            const bool hit = sphere_roots(oo, dd, V(R.a, R.b, R.c), R.d, tmin, RTW_FLT_MAX, t);
+            RTW_TAKE(hit, t, R.prim)
+            R = Rn;
+        }
+    }
+#undef RTW_TAKE
+    if (!GENERIC || (ANY_HIT && best_prim >= 0)) return;
+    // moving spheres (own motion transform per candidate): generic path
+    for (int k = 0; k < sc.n_generic; k++) {
+        const int pi = load_i32(sc.order + sc.n_vol + k);
+        const rtw_prim pr = load_prim(sc, pi);
+        v3 po, pd, mt;
+        object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+        float t;
+        if (prim_test(pr, po, pd, V(0.f, 0.f, 0.f), tmin, RTW_FLT_MAX, gather_time, g, t)) {
+            if (t < best_t || (!ANY_HIT && t == best_t && best_prim >= 0 && !best_is_vol && pi < best_prim)) {
+                best_t = t; best_prim = pi; best_is_vol = false;
+                if (ANY_HIT) return;
+            }
+        }
+    }
+}
+
+// ---- k_path's walk: the candidate lists in LDS ----------------------------------------------------------------------
+// The same groups, records and order as traverse_brute, copied by the workgroup into LDS at kernel start and read by
+// every lane of a wave at the same address (broadcast reads): an LDS round trip per candidate instead of a scalar-cache
+// one, which is what bounded k_path's walks (two thirds of their wave-cycles were s_waitcnt on s_load).
+// Image, in 16-byte words: groups (2 words each: BruteGroup), then per group the 3 rows of its world->object matrix,
+// then the records (2 words each: BruteRec). Arithmetic per ray: exactly traverse_brute's.
+constexpr int kWalkMaxWords = 400;  // 6.4 KB of LDS; scenes whose lists are larger use the wavefront kernels
+template <bool ANY_HIT>
+RTW_DEV void walk_lds(const u32x4* __restrict__ w, const int n_groups, const v3 o, const v3 d, const float tmin, const float tmax, float& best_t, int& best_prim) {
+    best_t = tmax;
+    best_prim = -1;
+#define RTW_TAKE(HIT_, T_, PI_)                                                                      \
+    {                                                                                                \
+        const bool tie_ = !ANY_HIT && ((T_) == best_t) & ((PI_) < best_prim);                        \
+        const bool take_ = (HIT_) & (((T_) < best_t) | tie_);                                        \
+        best_t = take_ ? (T_) : best_t;                                                              \
+        best_prim = take_ ? (PI_) : best_prim;                                                       \
+    }
+    const u32x4* xf = w + 2 * n_groups;
+    const u32x4* rec = w + 5 * n_groups;
+    for (int gi = 0; gi < n_groups; gi++) {
+        const u32x4 g0 = w[2 * gi], g1 = w[2 * gi + 1];
+        const int g_xform = (int)__builtin_amdgcn_readfirstlane(g0.x), first = (int)__builtin_amdgcn_readfirstlane(g0.y);
+        const int n_rx = (int)__builtin_amdgcn_readfirstlane(g0.z), n_ry = (int)__builtin_amdgcn_readfirstlane(g0.w);
+        const int n_rz = (int)__builtin_amdgcn_readfirstlane(g1.x), n_sph = (int)__builtin_amdgcn_readfirstlane(g1.y);
+        v3 oo = o, dd = d;
+        if (g_xform != 0) {
+            const u32x4 r0 = xf[3 * gi], r1 = xf[3 * gi + 1], r2 = xf[3 * gi + 2];
+            float m[12];
+            m[0] = __uint_as_float(r0.x); m[1] = __uint_as_float(r0.y); m[2] = __uint_as_float(r0.z); m[3] = __uint_as_float(r0.w);
+            m[4] = __uint_as_float(r1.x); m[5] = __uint_as_float(r1.y); m[6] = __uint_as_float(r1.z); m[7] = __uint_as_float(r1.w);
+            m[8] = __uint_as_float(r2.x); m[9] = __uint_as_float(r2.y); m[10] = __uint_as_float(r2.z); m[11] = __uint_as_float(r2.w);
+            oo = xf_point(m, o);
+            dd = xf_vector(m, d);
+        }
+        const u32x4* r = rec + 2 * first;
+        if (n_rx + n_ry + n_rz > 0) {
+            const v3 inv = recip3(dd);
+#define RTW_RECT_LOOP(N_, OK_, IK_, OA_, DA_, OB_, DB_)                                              \
+            for (int i = 0; i < (N_); i++, r += 2) {                                                 \
+                const u32x4 q0 = r[0], q1 = r[1];                                                    \
+                const float t = (__uint_as_float(q1.x) - (OK_)) * (IK_);                             \
+                const float a = fma_(t, (DA_), (OA_));                                               \
+                const float b = fma_(t, (DB_), (OB_));                                               \
+                const bool hit = (t >= tmin) & (a >= __uint_as_float(q0.x)) & (a <= __uint_as_float(q0.y)) & \
+                                 (b >= __uint_as_float(q0.z)) & (b <= __uint_as_float(q0.w));        \
+                RTW_TAKE(hit, t, (int)q1.y)                                                          \
+            }
+            RTW_RECT_LOOP(n_rx, oo.x, inv.x, oo.y, dd.y, oo.z, dd.z)   // shaders/aarectx.cu:8-22
+            RTW_RECT_LOOP(n_ry, oo.y, inv.y, oo.x, dd.x, oo.z, dd.z)   // shaders/aarecty.cu:8-22
+            RTW_RECT_LOOP(n_rz, oo.z, inv.z, oo.x, dd.x, oo.y, dd.y)   // shaders/aarectz.cu:9-23
+#undef RTW_RECT_LOOP
+        }
+        for (int i = 0; i < n_sph; i++, r += 2) {
+            const u32x4 q0 = r[0], q1 = r[1];
+            float t = 0.f;
+            const bool hit = sphere_roots(oo, dd, V(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)), __uint_as_float(q0.w), tmin, RTW_FLT_MAX, t);
+            RTW_TAKE(hit, t, (int)q1.y)
+        }
+    }
+#undef RTW_TAKE
+}
+
+// Closest / any hit (optixTraverse at raygen.cu:41-54 and closehit.cu:27-40).
+// Candidate order (observable only through volume RNG draws and exact ties in t): volume
+// primitives in index order, then everything else with ties resolved to the lowest index.
+// tm: this thread's column of the LDS traversal stack and the block's LDS node cache (trav_mem).
 template <class RNG, bool ANY_HIT, bool SKIP_VOLUMES>
 RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, float ray_time, float gather_time, RNG& g,
                       const TravMem& tm, float& best_t, int& best_prim) {
+    if (!sc.use_bvh) {
+        traverse_brute<RNG, ANY_HIT, SKIP_VOLUMES>(sc, o, d, tmin, tmax, ray_time, gather_time, g, best_t, best_prim);
+        return;
+    }
     best_t = tmax;
     best_prim = -1;
     // volumes first, in index order
@@ -662,64 +805,11 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
     }
     // The closest hit is the minimum over (t, primitive index) of the non-volume candidates, which is
     // what the oracle's index-order scan with a strict '<' yields; written this way the candidates
-    // may be visited in any order, so they are regrouped (brute lists) or culled (BVH) freely.
+    // may be visited in any order, so they are culled by the tree freely.
 #define RTW_ACCEPT(T_, PI_)                                                                          \
     if ((T_) < best_t || (!ANY_HIT && (T_) == best_t && best_prim >= 0 && !best_is_vol && (PI_) < best_prim)) { \
         best_t = (T_); best_prim = (PI_); best_is_vol = false;                                       \
         if (ANY_HIT) return;                                                                         \
-    }
-    if (!sc.use_bvh) {
-        // Small scenes: every lane walks the same candidate lists, so the records arrive through the
-        // scalar cache as SGPR operands. Per instance transform: one object-space ray, one reciprocal
-        // direction, then straight-line tests (rect x / y / z lists, spheres).
-        for (int gi = 0; gi < sc.n_groups; gi++) {
-            const BruteGroup G = load_group(sc, gi);
-            v3 oo = o, dd = d;
-            if (G.xform != 0) { M34 im = load_xf_inv(sc, G.xform); oo = xf_point(im.m, o); dd = xf_vector(im.m, d); }
-            int ri = G.first;
-            if (G.n_rx + G.n_ry + G.n_rz > 0) {
-                const v3 inv = recip3(dd);
-// straight-line candidate test: every comparison is evaluated, the update is one predicated select
-#define RTW_TAKE(HIT_, T_, PI_)                                                                      \
-                {                                                                                    \
-                    const bool tie_ = !ANY_HIT && ((T_) == best_t) & ((PI_) < best_prim) & !best_is_vol; \
-                    const bool take_ = (HIT_) & (((T_) < best_t) | tie_);                            \
-                    best_t = take_ ? (T_) : best_t;                                                  \
-                    best_prim = take_ ? (PI_) : best_prim;                                           \
-                    best_is_vol = take_ ? false : best_is_vol;                                       \
-                }
-#define RTW_RECT_LOOP(N_, OK_, IK_, OA_, DA_, OB_, DB_)                                              \
-                for (int i = 0; i < (N_); i++, ri++) {                                               \
-                    const BruteRec R = load_rec(sc, ri);                                             \
-                    const float t = (R.e - (OK_)) * (IK_);                                           \
-                    const float a = fma_(t, (DA_), (OA_));                                           \
-                    const float b = fma_(t, (DB_), (OB_));                                           \
-                    const bool hit = (t >= tmin) & (a >= R.a) & (a <= R.b) & (b >= R.c) & (b <= R.d); \
-                    RTW_TAKE(hit, t, R.prim)                                                         \
-                }
-                RTW_RECT_LOOP(G.n_rx, oo.x, inv.x, oo.y, dd.y, oo.z, dd.z)   // shaders/aarectx.cu:8-22
-                RTW_RECT_LOOP(G.n_ry, oo.y, inv.y, oo.x, dd.x, oo.z, dd.z)   // shaders/aarecty.cu:8-22
-                RTW_RECT_LOOP(G.n_rz, oo.z, inv.z, oo.x, dd.x, oo.y, dd.y)   // shaders/aarectz.cu:9-23
-#undef RTW_RECT_LOOP
-            }
-            for (int i = 0; i < G.n_sph; i++, ri++) {
-                const BruteRec R = load_rec(sc, ri);
-                float t = 0.f;
-                const bool hit = sphere_roots(oo, dd, V(R.a, R.b, R.c), R.d, tmin, RTW_FLT_MAX, t);
-                RTW_TAKE(hit, t, R.prim)
-            }
-#undef RTW_TAKE
-        }
-        // moving spheres (own motion transform per candidate): generic path
-        for (int k = 0; k < sc.n_generic; k++) {
-            const int pi = load_i32(sc.order + sc.n_vol + k);
-            const rtw_prim pr = load_prim(sc, pi);
-            v3 po, pd, mt;
-            object_ray(sc, pr, o, d, ray_time, po, pd, mt);
-            float t;
-            if (prim_test(pr, po, pd, V(0.f, 0.f, 0.f), tmin, RTW_FLT_MAX, gather_time, g, t)) { RTW_ACCEPT(t, pi) }
-        }
-        return;
     }
     if (sc.n_tree <= 0) return;
     // BVH2, "while-while" walk: a tight loop descends through inner nodes (one 64-byte record per step carries
@@ -813,21 +903,31 @@ RTW_DEV void traverse_dual_brute(const DScene& sc, const v3 o, const v3 dr, cons
     }
 }
 
-RTW_DEV HitRec load_hitrec(const DScene& sc, int prim) {
-    const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.hitrec + prim);
-    const u32x4 a = q[0], b = q[1], c = q[2];
+// lds: the workgroup's LDS copy of the hit records (k_path, small scenes), or nullptr: a divergent index then costs an
+// LDS read instead of a trip through the vector memory pipeline
+RTW_DEV HitRec load_hitrec(const DScene& sc, int prim, const u32x4* lds = nullptr) {
+    u32x4 a, b, c, d, e, f;
+    d = e = f = u32x4{0u, 0u, 0u, 0u};
+    bool basis;
+    if (lds != nullptr) {
+        const u32x4* q = lds + 6 * prim;
+        a = q[0]; b = q[1]; c = q[2];
+        basis = (int)(a.w & 127u) == HK_CONST_NORMAL && (int)a.x == RTW_MAT_LAMBERTIAN;
+        if (basis) { d = q[3]; e = q[4]; f = q[5]; }
+    } else {
+        const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.hitrec + prim);
+        a = q[0]; b = q[1]; c = q[2];
+        basis = (int)(a.w & 127u) == HK_CONST_NORMAL && (int)a.x == RTW_MAT_LAMBERTIAN;
+        if (basis) { d = q[3]; e = q[4]; f = q[5]; }
+    }
     HitRec h;
     h.mat_type = (int)a.x; h.bsdf_eval = (int)a.y; h.param = __uint_as_float(a.z); h.kind = (int)(a.w & 127u); h.listed = (int)((a.w >> 7) & 1u); h.tex_dyn = (int)(a.w >> 8) - 1;
     h.r = __uint_as_float(b.x); h.g = __uint_as_float(b.y); h.b = __uint_as_float(b.z); h.inv_r = __uint_as_float(b.w);
     h.nx = __uint_as_float(c.x); h.ny = __uint_as_float(c.y); h.nz = __uint_as_float(c.z); h.xform = (int)c.w;
-    h.ux = h.uy = h.uz = h.vx = h.vy = h.vz = h.wx = h.wy = h.wz = 0.f;
+    h.ux = __uint_as_float(d.x); h.uy = __uint_as_float(d.y); h.uz = __uint_as_float(d.z);
+    h.vx = __uint_as_float(e.x); h.vy = __uint_as_float(e.y); h.vz = __uint_as_float(e.z);
+    h.wx = __uint_as_float(f.x); h.wy = __uint_as_float(f.y); h.wz = __uint_as_float(f.z);
     h.pad2 = 0.f;
-    if (h.kind == HK_CONST_NORMAL && h.mat_type == RTW_MAT_LAMBERTIAN) {
-        const u32x4 d = q[3], e = q[4], f = q[5];
-        h.ux = __uint_as_float(d.x); h.uy = __uint_as_float(d.y); h.uz = __uint_as_float(d.z);
-        h.vx = __uint_as_float(e.x); h.vy = __uint_as_float(e.y); h.vz = __uint_as_float(e.z);
-        h.wx = __uint_as_float(f.x); h.wy = __uint_as_float(f.y); h.wz = __uint_as_float(f.z);
-    }
     return h;
 }
 

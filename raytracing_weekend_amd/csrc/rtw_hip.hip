@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtw.h"
@@ -61,12 +62,22 @@ struct rtw_ctx {
         size_t cnt_words = 0;
         size_t paths = 0;
     } lane[4];
-    float4* accum = nullptr;
+    float4* accum = nullptr;   // per pixel: sum of the finished sample blocks
+    float4* part = nullptr;    // per pixel: running sum of the current block (wavefront pipeline)
     size_t accum_pix = 0;
+    float4* blocksum = nullptr;  // k_path: [block][pixel] unit sums of one pass
+    size_t blocksum_elems = 0;
+    uint32_t* d_queue = nullptr; // k_path: job counter
+    std::vector<hipEvent_t> ev_pool;  // timing events, reused across launches and calls
     unsigned long long* d_stats = nullptr;
     float4* d_out = nullptr;
     size_t out_pix = 0;
     int n_cu = 256;
+    // n_devices > 1: this context is a group; kids[g] renders the g-th interleaved sub-shard on device_ids[g], the
+    // shards are gathered on device_ids[0] (this->device) into `stage` and interleaved into the caller's frame
+    std::vector<rtw_ctx*> kids;
+    float4* stage = nullptr;
+    size_t stage_pix = 0;
 };
 
 namespace {
@@ -139,13 +150,17 @@ int ensure_pool(rtw_ctx* c, int n_lanes, size_t paths, size_t npix, size_t cnt_w
         int rc = ensure_lane(c, c->lane[l], paths, cnt_words);
         if (rc) return rc;
     }
+    if (n_lanes == 0 && !c->d_queue) HIP_TRY(c, hipMalloc(&c->d_queue, 64));
     if (npix > c->accum_pix) {
         if (c->accum) (void)hipFree(c->accum);
         c->accum = nullptr; c->accum_pix = 0;
         HIP_TRY(c, hipMalloc(&c->accum, npix * sizeof(float4)));
+        if (c->part) (void)hipFree(c->part);
+        c->part = nullptr;
+        HIP_TRY(c, hipMalloc(&c->part, npix * sizeof(float4)));
         c->accum_pix = npix;
     }
-    if (!c->d_stats) HIP_TRY(c, hipMalloc(&c->d_stats, kStatRows * 8 * sizeof(unsigned long long)));
+    if (!c->d_stats) HIP_TRY(c, hipMalloc(&c->d_stats, (kStatRows + 1) * 8 * sizeof(unsigned long long)));
     return RTW_OK;
 }
 
@@ -169,6 +184,12 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_LDS_KB      dynamic LDS per workgroup for traversal stacks + staged tree nodes (default 16)
 //   RTW_TAIL_GROUP  bounces per launch of the first tail group (default 2; groups grow by half every second launch)
 //   RTW_STAGGER     size of the second lane's first batch in percent of a full batch (default 50; 0 = no offset)
+//   RTW_PATH        1 (default): scenes walked with the brute lists render through k_path (paths in registers, in-wave
+//                   regeneration); 0: always the wavefront pipeline
+//   RTW_PATH_JOB_BLOCKS  sample blocks per k_path job (default 2: a job is 64 pixels x 128 samples)
+//   RTW_PATH_GRID_MULT   k_path workgroups per CU (default: what the occupancy query admits)
+//   RTW_BLOCKSUM_BYTES   cap of the k_path block-sum buffer (default 16 GiB); larger renders run in passes over the samples
+//   RTW_KERNEL_TIMING    0: no per-launch events even when the caller asks for rtw_stats (kernel_seconds stay 0)
 struct Tuning {
     size_t pool_paths = (size_t)1 << 28;
     int lanes = 2;
@@ -180,6 +201,11 @@ struct Tuning {
     size_t lds_kb = 16;
     int stagger_pct = 50;
     int tail_group = 2;
+    int path = 1;
+    int path_job_blocks = 2;
+    int path_grid_mult = 0;
+    size_t blocksum_bytes = (size_t)16 << 30;
+    bool kernel_timing = true;
 };
 Tuning read_tuning() {
     Tuning t;
@@ -200,10 +226,15 @@ Tuning read_tuning() {
     if (geti("RTW_LDS_KB", v)) t.lds_kb = (size_t)std::max<long long>(0, v);
     if (geti("RTW_TAIL_GROUP", v)) t.tail_group = (int)std::max<long long>(1, std::min<long long>(64, v));
     if (geti("RTW_STAGGER", v)) t.stagger_pct = (int)std::max<long long>(0, std::min<long long>(99, v));
+    if (geti("RTW_PATH", v)) t.path = (int)std::max<long long>(0, std::min<long long>(2, v));
+    if (geti("RTW_PATH_JOB_BLOCKS", v)) t.path_job_blocks = (int)std::max<long long>(1, std::min<long long>(1024, v));
+    if (geti("RTW_PATH_GRID_MULT", v)) t.path_grid_mult = (int)std::max<long long>(1, std::min<long long>(16, v));
+    if (geti("RTW_BLOCKSUM_BYTES", v) && v >= (1 << 16)) t.blocksum_bytes = (size_t)v;
+    if (geti("RTW_KERNEL_TIMING", v)) t.kernel_timing = v != 0;
     return t;
 }
 
-enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE };
+enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE, LK_PATH = RTW_K_PATH };
 void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s) {
     const bool lcg = rng_kind == RTW_RNG_TEA_LCG;
     // kernels that shade exist in four instantiations: RNG kind x "some material has a non-constant texture"
@@ -223,6 +254,7 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
         else if (a.sc.n_generic == 0) hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(kBlock), lds, s, a);
         else hipLaunchKernelGGL((k_trace<false>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
+    case LK_PATH: RTW_LAUNCH_SHADING(k_path, lds); break;
     default: RTW_LAUNCH_SHADING(k_bounce, lds); break;
 #undef RTW_LAUNCH_SHADING
     }
@@ -236,13 +268,10 @@ int rtw_abi_version(void) { return RTW_ABI_VERSION; }
 
 const char* rtw_last_error(rtw_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
-int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids) {
-    if (!out) return RTW_ERR_INVALID_ARG;
-    *out = nullptr;
-    if (n_devices != 1) return RTW_ERR_UNSUPPORTED;  // one context per GPU; ranks are separate processes
+static int create_single(rtw_ctx** out, int device) {
     rtw_ctx* c = new (std::nothrow) rtw_ctx();
     if (!c) return RTW_ERR_OOM;
-    c->device = device_ids ? device_ids[0] : 0;
+    c->device = device;
     hipError_t e = hipSetDevice(c->device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) {
@@ -255,8 +284,39 @@ int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids) {
     return RTW_OK;
 }
 
+int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids) {
+    if (!out) return RTW_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (n_devices < 1 || n_devices > 64) return RTW_ERR_INVALID_ARG;
+    rtw_ctx* c = nullptr;
+    int rc = create_single(&c, device_ids ? device_ids[0] : 0);
+    if (rc) return rc;
+    if (n_devices > 1) {
+        // a group: one single-device context per entry of device_ids (entries may repeat: two shards on one GPU)
+        for (int g = 0; g < n_devices; g++) {
+            rtw_ctx* k = nullptr;
+            rc = create_single(&k, device_ids ? device_ids[g] : g);
+            if (rc) { rtw_destroy(c); return rc; }
+            c->kids.push_back(k);
+            if (k->device != c->device) {  // direct peer copies for the gather where the link allows them; not an error if not
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, c->device, k->device) == hipSuccess && can) {
+                    (void)hipSetDevice(c->device);
+                    (void)hipDeviceEnablePeerAccess(k->device, 0);
+                    (void)hipGetLastError();  // hipErrorPeerAccessAlreadyEnabled is fine
+                }
+            }
+        }
+        (void)hipSetDevice(c->device);
+    }
+    *out = c;
+    return RTW_OK;
+}
+
 int rtw_destroy(rtw_ctx* c) {
     if (!c) return RTW_ERR_INVALID_ARG;
+    for (rtw_ctx* k : c->kids) (void)rtw_destroy(k);
+    c->kids.clear();
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_pool(c);
@@ -265,7 +325,12 @@ int rtw_destroy(rtw_ctx* c) {
         if (L.ev_free) (void)hipEventDestroy(L.ev_free);
         if (L.st) (void)hipStreamDestroy(L.st);
     }
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->accum) (void)hipFree(c->accum);
+    if (c->part) (void)hipFree(c->part);
+    if (c->blocksum) (void)hipFree(c->blocksum);
+    if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->stage) (void)hipFree(c->stage);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_scene) (void)hipFree(c->d_scene);
@@ -276,10 +341,19 @@ int rtw_destroy(rtw_ctx* c) {
 
 int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!c) return RTW_ERR_INVALID_ARG;
+    if (!c->kids.empty()) {  // group: every device gets its own copy of the scene tables and the tree
+        c->has_scene = false;
+        for (rtw_ctx* k : c->kids) {
+            const int rc = rtw_upload_scene(k, blob, bytes);
+            if (rc) return fail(c, rc, k->err);
+        }
+        c->has_scene = true;
+        return RTW_OK;
+    }
     if (!blob || bytes < sizeof(rtw_scene_header)) return fail(c, RTW_ERR_BAD_SCENE, "scene blob too small");
     rtw_scene_header h;
     memcpy(&h, blob, sizeof h);
-    if (h.magic != RTW_SCENE_MAGIC || h.version != RTW_ABI_VERSION || h.total_bytes > bytes)
+    if (h.magic != RTW_SCENE_MAGIC || h.version != RTW_SCENE_VERSION || h.total_bytes > bytes)
         return fail(c, RTW_ERR_BAD_SCENE, "bad scene header (magic/version/size)");
     auto in_range = [&](uint32_t off, uint32_t n, size_t sz) { return (size_t)off + (size_t)n * sz <= bytes; };
     if (!in_range(h.off_prims, h.n_prims, sizeof(rtw_prim)) || !in_range(h.off_xforms, h.n_xforms, sizeof(rtw_xform)) ||
@@ -456,6 +530,17 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
             groups.push_back(g);
         }
     }
+    // k_path's LDS image of the same lists (rtw_device.h walk_lds): groups, their world->object matrices, records
+    std::vector<uint32_t> walk;
+    if (!use_bvh && n_generic == 0 && !groups.empty()) {
+        static_assert(sizeof(BruteGroup) == 32 && sizeof(BruteRec) == 32, "walk image layout");
+        const size_t ng = groups.size();
+        walk.resize((5 * ng + 2 * recs.size()) * 4, 0u);
+        memcpy(walk.data(), groups.data(), ng * sizeof(BruteGroup));
+        for (size_t g = 0; g < ng; g++) memcpy(walk.data() + (2 * ng + 3 * g) * 4, xforms[groups[g].xform].inv, 12 * sizeof(float));
+        if (!recs.empty()) memcpy(walk.data() + 5 * ng * 4, recs.data(), recs.size() * sizeof(BruteRec));
+        if (walk.size() / 4 > (size_t)kWalkMaxWords) walk.clear();
+    }
     rtwbvh::Bvh bvh;
     if (use_bvh) {
         bvh = rtwbvh::build_bvh(prims.data(), h.n_prims, xforms.data());
@@ -474,9 +559,10 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     size_t o_order = al(o_tree + std::max<size_t>(1, bvh.prim_order.size()) * sizeof(int32_t));
     size_t o_groups = al(o_order + std::max<size_t>(1, order.size()) * sizeof(int32_t));
     size_t o_recs = al(o_groups + std::max<size_t>(1, groups.size()) * sizeof(BruteGroup));
-    size_t o_texs = al(o_recs + std::max<size_t>(1, recs.size()) * sizeof(BruteRec));
+    size_t o_texs = al(o_recs + (recs.size() + 1) * sizeof(BruteRec));  // + 1: traverse_brute reads one record ahead
     size_t o_texdata = al(o_texs + std::max<size_t>(1, texs.size()) * sizeof(rtw_texture));
-    size_t total = al(o_texdata + std::max<size_t>(1, texdata.size()) * sizeof(uint32_t));
+    size_t o_walk = al(o_texdata + std::max<size_t>(1, texdata.size()) * sizeof(uint32_t));
+    size_t total = al(o_walk + std::max<size_t>(1, walk.size()) * sizeof(uint32_t));
     std::vector<char> stage(total, 0);
     if (!prims.empty()) memcpy(stage.data() + o_prims, prims.data(), prims.size() * sizeof(rtw_prim));
     memcpy(stage.data() + o_xf, xforms.data(), xforms.size() * sizeof(rtw_xform));
@@ -491,6 +577,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!recs.empty()) memcpy(stage.data() + o_recs, recs.data(), recs.size() * sizeof(BruteRec));
     if (!texs.empty()) memcpy(stage.data() + o_texs, texs.data(), texs.size() * sizeof(rtw_texture));
     if (!texdata.empty()) memcpy(stage.data() + o_texdata, texdata.data(), texdata.size() * sizeof(uint32_t));
+    if (!walk.empty()) memcpy(stage.data() + o_walk, walk.data(), walk.size() * sizeof(uint32_t));
 
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -513,6 +600,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.recs = (const BruteRec*)(d + o_recs);
     sc.texs = (const rtw_texture*)(d + o_texs);
     sc.texdata = (const uint32_t*)(d + o_texdata);
+    sc.walk = (const u32x4*)(d + o_walk);
+    sc.n_walk_words = (int32_t)(walk.size() / 4);
     sc.noise_lds_data = -1;  // the first noise texture some primitive shows gets its tables staged in LDS
     for (uint32_t i = 0; i < h.n_prims && sc.noise_lds_data < 0; i++) {
         int ti = mats[prims[i].material].texture;
@@ -520,7 +609,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         if (texs[ti].type == RTW_TEX_CHECKER) ti = texs[texs[ti].odd].type == RTW_TEX_NOISE ? texs[ti].odd : texs[ti].even;
         if (texs[ti].type == RTW_TEX_NOISE) sc.noise_lds_data = (int32_t)texs[ti].data;
     }
-    sc.has_tex = (has_tex || n_vol > 0) ? 1 : 0;  // selects the kernel instantiations that contain the texture and media code
+    // selects the kernel instantiations that contain the cold features: textures, media, (k_path) moving spheres in the brute lists
+    sc.has_tex = (has_tex || n_vol > 0 || n_generic > 0) ? 1 : 0;
     sc.n_groups = (int)groups.size();
     sc.n_generic = n_generic;
     sc.n_prims = (int)h.n_prims;
@@ -558,27 +648,141 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     return RTW_OK;
 }
 
-int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_stream, rtw_stats* stats) {
-    if (!c) return RTW_ERR_INVALID_ARG;
+static int check_render_args(rtw_ctx* c, const rtw_params* P) {
     if (!c->has_scene) return fail(c, RTW_ERR_NO_SCENE, "rtw_render before rtw_upload_scene");
-    if (!P || !d_rgba) return fail(c, RTW_ERR_INVALID_ARG, "null params or output");
+    if (!P) return fail(c, RTW_ERR_INVALID_ARG, "null params");
     if (P->width <= 0 || P->height <= 0 || P->spp <= 0 || P->max_depth < 0 || P->row0 < 0 || P->row1 > P->height || P->row0 > P->row1)
         return fail(c, RTW_ERR_INVALID_ARG, "bad render params");
     if (P->rng_kind != RTW_RNG_PHILOX && P->rng_kind != RTW_RNG_TEA_LCG) return fail(c, RTW_ERR_INVALID_ARG, "bad rng_kind");
     if (P->sample_offset < 0 || P->samples_per_pass < 0 || P->row_stride < 0) return fail(c, RTW_ERR_INVALID_ARG, "bad sample_offset/samples_per_pass/row_stride");
     if (P->estimator < RTW_EST_REFERENCE || P->estimator > RTW_EST_CORRECTED_NO_NEE) return fail(c, RTW_ERR_INVALID_ARG, "bad estimator");
+    return RTW_OK;
+}
+
+static size_t shard_rows(const rtw_params* P) {
+    const size_t k = P->row_stride > 1 ? (size_t)P->row_stride : 1;
+    return ((size_t)(P->row1 - P->row0) + k - 1) / k;
+}
+
+// One device: the whole render of the shard P describes, result in d_rgba (device memory of c->device).
+static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, rtw_stats* stats) {
     HIP_TRY(c, hipSetDevice(c->device));
-    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (!s) s = c->stream;
 
     const uint32_t row_stride = P->row_stride > 1 ? (uint32_t)P->row_stride : 1u;
-    const size_t rows = ((size_t)(P->row1 - P->row0) + row_stride - 1) / row_stride;
+    const size_t rows = shard_rows(P);
     const size_t npix = rows * (size_t)P->width;
     if (stats) memset(stats, 0, sizeof *stats);
     if (npix == 0) return RTW_OK;
     if (npix > 0xffffffffull / 2) return fail(c, RTW_ERR_UNSUPPORTED, "tile too large");
 
-    // samples per pass: keep about pool_target paths in flight, split over the lanes
     const Tuning tune = read_tuning();
+    const bool timing = stats != nullptr && tune.kernel_timing;
+    // timing events come from a pool kept in the context: (kernel kind, start, stop) triples of this call
+    size_t ev_used = 0;
+    auto new_event = [&](hipEvent_t& e) -> hipError_t {
+        if (ev_used == c->ev_pool.size()) {
+            hipEvent_t n = nullptr;
+            hipError_t er = hipEventCreate(&n);
+            if (er != hipSuccess) return er;
+            c->ev_pool.push_back(n);
+        }
+        e = c->ev_pool[ev_used++];
+        return hipSuccess;
+    };
+    struct Timed { int kind; hipEvent_t a, b; };
+    std::vector<Timed> ev_k;
+    auto timed_launch = [&](hipStream_t ls, int kind, const KArgs& ka, int grid_, size_t lds_) -> hipError_t {
+        if (!timing) {
+            launch(kind, P->rng_kind, ka, grid_, lds_, ls);
+            return hipSuccess;
+        }
+        Timed t{kind, nullptr, nullptr};
+        hipError_t er = new_event(t.a);
+        if (er == hipSuccess) er = new_event(t.b);
+        if (er == hipSuccess) er = hipEventRecord(t.a, ls);
+        if (er != hipSuccess) return er;
+        launch(kind, P->rng_kind, ka, grid_, lds_, ls);
+        ev_k.push_back(t);
+        return hipEventRecord(t.b, ls);
+    };
+#define HIP_TRY_C(expr) HIP_TRY(c, expr)
+    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
+    HIP_TRY_C(new_event(ev_begin));
+    HIP_TRY_C(new_event(ev_end));
+
+    // kernel arguments common to both pipelines
+    KArgs base{};
+    base.sc = c->sc;
+    if (P->estimator != RTW_EST_REFERENCE) {  // the corrected estimators live in the cold-feature instantiations
+        base.sc.estimator = P->estimator; base.sc.has_tex = 1;
+        base.sc.ray_tmin = 1.0e-3f; base.sc.probe_eps = 1.0e-3f;
+    }
+    base.npix = (uint32_t)npix;
+    base.width = (uint32_t)P->width;
+    base.height = (uint32_t)P->height;
+    base.row0 = (uint32_t)P->row0;
+    base.row_stride = row_stride;
+    magic_div((uint32_t)P->width, base.divw_m, base.divw_s1, base.divw_s2);
+    magic_div(row_stride, base.divs_m, base.divs_s1, base.divs_s2);
+    base.seed = P->seed;
+    base.max_depth = (uint32_t)P->max_depth;
+    base.stack_stride = kBlock;
+    base.spp = (uint32_t)P->spp;
+    const size_t lds = c->lds_bytes;
+    const unsigned pix_grid = (unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, (size_t)c->n_cu * 8);
+    uint64_t launches = 0;
+    const bool use_path = P->max_depth > 0 && tune.path != 0 && !c->sc.use_bvh && c->sc.n_prims <= kPathMaxPrims && (c->sc.n_walk_words > 0 || c->sc.has_tex);
+
+    if (use_path) {
+        // ---- k_path: paths in registers, lanes regenerate; only the unit sums (16 B per pixel and 64 samples) reach HBM
+        int rc = ensure_pool(c, 0, 0, npix, 0);
+        if (rc) return rc;
+        const size_t n_blocks = ((size_t)P->spp + kSumBlock - 1) / kSumBlock;
+        const size_t pass_blocks = std::min<size_t>(n_blocks, std::max<size_t>(1, tune.blocksum_bytes / (npix * sizeof(float4))));
+        if (pass_blocks * npix > c->blocksum_elems) {
+            if (c->blocksum) (void)hipFree(c->blocksum);
+            c->blocksum = nullptr; c->blocksum_elems = 0;
+            HIP_TRY(c, hipMalloc(&c->blocksum, pass_blocks * npix * sizeof(float4)));
+            c->blocksum_elems = pass_blocks * npix;
+        }
+        int wg_per_cu = tune.path_grid_mult;
+        if (wg_per_cu <= 0) {
+            const bool lcg = P->rng_kind == RTW_RNG_TEA_LCG, tex = base.sc.has_tex != 0;
+            int nb = 0;
+            hipError_t qe = lcg ? (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_TEA_LCG, true>, kBlock, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_TEA_LCG, false>, kBlock, 0))
+                                : (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_PHILOX, true>, kBlock, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_PHILOX, false>, kBlock, 0));
+            wg_per_cu = (qe == hipSuccess && nb > 0) ? std::min(nb, 8) : 4;
+        }
+        HIP_TRY_C(hipEventRecord(ev_begin, s));
+        HIP_TRY_C(hipMemsetAsync(c->accum, 0, npix * sizeof(float4), s));
+        HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, (kStatRows + 1) * 8 * sizeof(unsigned long long), s));
+        const size_t n_groups = (npix + 63) / 64;
+        for (size_t b0 = 0; b0 < n_blocks; b0 += pass_blocks) {
+            const size_t nb = std::min(pass_blocks, n_blocks - b0);
+            const size_t jb = std::min<size_t>((size_t)tune.path_job_blocks, nb);
+            const size_t n_ranges = (nb + jb - 1) / jb;
+            const size_t n_jobs = n_groups * n_ranges;
+            if (n_jobs > 0xfffffff0ull) return fail(c, RTW_ERR_UNSUPPORTED, "too many k_path jobs");
+            KArgs a = base;
+            a.stats = c->d_stats;
+            a.sample0 = (uint32_t)P->sample_offset;
+            a.queue = c->d_queue;
+            a.blocksum = c->blocksum;
+            a.n_jobs = (uint32_t)n_jobs; a.n_ranges = (uint32_t)n_ranges; a.blocks_per_job = (uint32_t)jb;
+            a.block0 = (uint32_t)b0; a.n_blocks_pass = (uint32_t)nb;
+            HIP_TRY_C(hipMemsetAsync(c->d_queue, 0, 64, s));
+            const int grid = (int)std::min<size_t>((size_t)c->n_cu * (size_t)wg_per_cu, (n_jobs + 3) / 4);
+            HIP_TRY_C(timed_launch(s, LK_PATH, a, grid, 0));
+            launches++;
+            hipLaunchKernelGGL(k_resolve_blocks, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->blocksum, c->accum, (uint32_t)npix, (uint32_t)nb);
+        }
+        hipLaunchKernelGGL(k_finish, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->accum, (const float4*)nullptr, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);
+    } else {
+    // ---- wavefront pipeline (tree scenes; RTW_PATH=0)
+    // samples per pass: keep about pool_target paths in flight, split over the lanes
     const int want_lanes = tune.lanes;
     size_t S = P->samples_per_pass > 0 ? (size_t)P->samples_per_pass
                                        : std::max<size_t>(1, tune.pool_paths / (size_t)want_lanes / npix);
@@ -638,50 +842,16 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
     int rc = ensure_pool(c, n_lanes, (size_t)regions_max * region_cap_max, npix, cnt_words);
     if (rc) return rc;
-    hipEvent_t ev_begin = nullptr, ev_end = nullptr;
-    HIP_TRY(c, hipEventCreate(&ev_begin));
-    HIP_TRY(c, hipEventCreate(&ev_end));
-    std::vector<hipEvent_t> ev_loop;
-    std::vector<std::pair<int, hipEvent_t>> ev_k;  // (kernel kind, event) pairs: start, stop, start, stop ...
-    auto cleanup = [&]() {
-        (void)hipEventDestroy(ev_begin);
-        (void)hipEventDestroy(ev_end);
-        for (hipEvent_t e : ev_loop) (void)hipEventDestroy(e);
-        for (auto& e : ev_k) (void)hipEventDestroy(e.second);
-    };
-    auto timed_launch = [&](hipStream_t ls, int kind, const KArgs& ka, int grid_, size_t lds_) -> hipError_t {
-        hipEvent_t a_ = nullptr, b_ = nullptr;
-        hipError_t er = hipEventCreate(&a_);
-        if (er != hipSuccess) return er;
-        ev_k.push_back({kind, a_});
-        er = hipEventCreate(&b_);
-        if (er != hipSuccess) return er;
-        ev_k.push_back({kind, b_});
-        er = hipEventRecord(a_, ls);
-        if (er != hipSuccess) return er;
-        launch(kind, P->rng_kind, ka, grid_, lds_, ls);
-        return hipEventRecord(b_, ls);
-    };
-#define HIP_TRY_C(expr)                                                               \
-    do {                                                                              \
-        hipError_t e_ = (expr);                                                       \
-        if (e_ != hipSuccess) {                                                       \
-            cleanup();                                                                \
-            return fail(c, RTW_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
-        }                                                                             \
-    } while (0)
 
     HIP_TRY_C(hipEventRecord(ev_begin, s));
     HIP_TRY_C(hipMemsetAsync(c->accum, 0, npix * sizeof(float4), s));
+    HIP_TRY_C(hipMemsetAsync(c->part, 0, npix * sizeof(float4), s));
     HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, kStatRows * 8 * sizeof(unsigned long long), s));
 
-    const size_t lds = c->lds_bytes;
-    uint64_t launches = 0;
     if (P->max_depth > 0) {
         // the lanes start once the accumulators are cleared
         hipEvent_t ev_ready = nullptr;
-        HIP_TRY_C(hipEventCreateWithFlags(&ev_ready, hipEventDisableTiming));
-        ev_loop.push_back(ev_ready);
+        HIP_TRY_C(new_event(ev_ready));
         HIP_TRY_C(hipEventRecord(ev_ready, s));
         size_t bi = 0;
         // The second lane's first batch is cut short so that the lanes run half a batch apart: one lane's bandwidth-bound
@@ -701,27 +871,12 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             // this lane's pool is free again once the resolve of its previous batch has run on the main stream
             HIP_TRY_C(hipStreamWaitEvent(ls, bi < (size_t)n_lanes ? ev_ready : L.ev_free, 0));
             HIP_TRY_C(hipMemsetAsync(L.cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), ls));
-            KArgs a{};
-            a.sc = c->sc;
-            if (P->estimator != RTW_EST_REFERENCE) {  // the corrected estimators live in the cold-feature instantiations
-                a.sc.estimator = P->estimator; a.sc.has_tex = 1;
-                a.sc.ray_tmin = 1.0e-3f; a.sc.probe_eps = 1.0e-3f;
-            }
+            KArgs a = base;
             a.lbuf = L.lbuf;
             a.stats = c->d_stats;
             a.n_regions = regions;
             a.n_paths = (uint32_t)paths;
-            a.npix = (uint32_t)npix;
-            a.width = (uint32_t)P->width;
-            a.height = (uint32_t)P->height;
-            a.row0 = (uint32_t)P->row0;
-            a.row_stride = row_stride;
-            magic_div((uint32_t)P->width, a.divw_m, a.divw_s1, a.divw_s2);
-            magic_div(row_stride, a.divs_m, a.divs_s1, a.divs_s2);
             a.sample0 = (uint32_t)(P->sample_offset + (int)s0);
-            a.seed = P->seed;
-            a.max_depth = (uint32_t)P->max_depth;
-            a.stack_stride = kBlock;
             a.region_cap = (uint32_t)region_cap;
             a.trace_first = split_first ? 1u : 0u;
             const int grid = (int)regions;  // every compacting launch uses exactly this grid: workgroup b owns region b
@@ -757,24 +912,35 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
             HIP_TRY_C(hipEventRecord(L.ev_done, ls));
             // batches are resolved into the accumulators in order, on the main stream
             HIP_TRY_C(hipStreamWaitEvent(s, L.ev_done, 0));
-            hipLaunchKernelGGL(k_resolve, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, (size_t)c->n_cu * 8)), dim3(kBlock), 0, s,
-                               (const float4*)L.lbuf, c->accum, (uint32_t)npix, (uint32_t)Sb);
+            hipLaunchKernelGGL(k_resolve, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)L.lbuf, c->accum, c->part, (uint32_t)npix, (uint32_t)Sb, (uint32_t)s0);
             HIP_TRY_C(hipEventRecord(L.ev_free, s));
         }
     }
-    hipLaunchKernelGGL(k_finish, dim3((unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, (size_t)c->n_cu * 8)), dim3(kBlock), 0, s,
-                       (const float4*)c->accum, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);
+    hipLaunchKernelGGL(k_finish, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->accum, (const float4*)c->part, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);
+    }
     HIP_TRY_C(hipGetLastError());
     HIP_TRY_C(hipEventRecord(ev_end, s));
     HIP_TRY_C(hipEventSynchronize(ev_end));
 
     unsigned long long hs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     {
-        unsigned long long rows[kStatRows * 8];
-        HIP_TRY_C(hipMemcpy(rows, c->d_stats, sizeof rows, hipMemcpyDeviceToHost));
+        unsigned long long rows_[kStatRows * 8];
+        HIP_TRY_C(hipMemcpy(rows_, c->d_stats, sizeof rows_, hipMemcpyDeviceToHost));
         for (uint32_t r = 0; r < kStatRows; r++)
-            for (int k = 0; k < 8; k++) hs[k] += rows[r * 8 + k];
+            for (int k = 0; k < 8; k++) hs[k] += rows_[r * 8 + k];
     }
+#ifdef RTW_PHASE_TIMERS
+    if (use_path) {
+        unsigned long long ph[8];
+        HIP_TRY_C(hipMemcpy(ph, c->d_stats + kStatRows * 8, sizeof ph, hipMemcpyDeviceToHost));
+        double tot = 0;
+        for (int q = 0; q < 6; q++) tot += (double)ph[q];
+        const char* nm[6] = {"refill", "regen", "walk_r", "shade_a", "walk_s", "shade_b"};
+        fprintf(stderr, "[rtw] k_path wave-cycles by phase:");
+        for (int q = 0; q < 6; q++) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * (double)ph[q] / tot);
+        fprintf(stderr, " (total %.3g wave-cycles, %.0f per 64 segments)\n", tot, tot / ((double)hs[0] / 64.0));
+    }
+#endif
 #ifdef RTW_TRACE_COUNT
     fprintf(stderr, "[rtw] k_trace_bvh: rays %llu inner steps %llu prim tests %llu outer iterations(wave) %llu\n", hs[2 + RTW_K_TRACE], hs[6], hs[7], hs[2 + RTW_K_BOUNCE]);
 #endif
@@ -783,11 +949,11 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         HIP_TRY_C(hipEventElapsedTime(&ms, ev_begin, ev_end));
         stats->seconds = (double)ms * 1e-3;
         stats->bounce_seconds = stats->seconds;  // the lanes overlap: the loop time is the elapsed time of the call
-        for (size_t i = 0; i + 1 < ev_k.size(); i += 2) {
+        for (const Timed& t : ev_k) {
             float m = 0.f;
-            HIP_TRY_C(hipEventElapsedTime(&m, ev_k[i].second, ev_k[i + 1].second));
-            stats->kernel_seconds[ev_k[i].first] += (double)m * 1e-3;
-            stats->kernel_launches[ev_k[i].first]++;
+            HIP_TRY_C(hipEventElapsedTime(&m, t.a, t.b));
+            stats->kernel_seconds[t.kind] += (double)m * 1e-3;
+            stats->kernel_launches[t.kind]++;
         }
         for (int k = 0; k < RTW_K_COUNT; k++) stats->kernel_segments[k] = hs[2 + k];
         stats->bounce_launches = launches;
@@ -796,9 +962,101 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
         stats->shadow_rays = hs[1];
         stats->algorithmic_bytes = 128ull * stats->segments + 32ull * stats->samples;
     }
-    cleanup();
 #undef HIP_TRY_C
     return RTW_OK;
+}
+
+// rows of the gathered shards -> rows of the frame: frame row r is row r / n of shard r % n
+__global__ void __launch_bounds__(256) k_interleave(const float4* __restrict__ stage, float4* __restrict__ out, uint32_t width, uint32_t rows, uint32_t n,
+                                                    const uint32_t* __restrict__ shard_off) {
+    const size_t total = (size_t)rows * width;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / width), x = (uint32_t)(i - (size_t)r * width);
+        const uint32_t g = r % n, l = r / n;
+        out[i] = stage[((size_t)shard_off[g] + l) * width + x];
+    }
+}
+
+// n_devices > 1: kid g renders rows row0 + g*k, row0 + (g + n)*k ... of the shard (k = the caller's row stride) on its own
+// device and host thread; the float4 shards are then gathered on device_ids[0] with one hipMemcpyPeerAsync each
+// (single process: the peer copies are the xGMI transfers an RCCL send/recv pair would issue) and interleaved.
+static int render_group(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, rtw_stats* stats) {
+    const size_t n = c->kids.size();
+    const size_t k = P->row_stride > 1 ? (size_t)P->row_stride : 1;
+    const size_t rows = shard_rows(P);
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (rows == 0) return RTW_OK;
+    std::vector<rtw_params> kp(n, *P);
+    std::vector<size_t> krows(n, 0);
+    std::vector<uint32_t> off(n + 1, 0);
+    for (size_t g = 0; g < n; g++) {
+        kp[g].row0 = P->row0 + (int32_t)(g * k);
+        kp[g].row_stride = (int32_t)(k * n);
+        krows[g] = rows > g ? (rows - g + n - 1) / n : 0;
+        if (kp[g].row0 > kp[g].row1) kp[g].row0 = kp[g].row1;
+        off[g + 1] = off[g] + (uint32_t)krows[g];
+    }
+    std::vector<int> rcs(n, RTW_OK);
+    std::vector<rtw_stats> kst(n);
+    std::vector<std::thread> th;
+    for (size_t g = 0; g < n; g++) {
+        th.emplace_back([&, g]() {
+            rtw_ctx* kc = c->kids[g];
+            const size_t npix = krows[g] * (size_t)P->width;
+            if (hipSetDevice(kc->device) != hipSuccess) { rcs[g] = fail(kc, RTW_ERR_DEVICE, "hipSetDevice failed"); return; }
+            if (npix > kc->out_pix) {
+                if (kc->d_out) (void)hipFree(kc->d_out);
+                kc->d_out = nullptr; kc->out_pix = 0;
+                if (hipMalloc(&kc->d_out, std::max<size_t>(npix, 1) * sizeof(float4)) != hipSuccess) { rcs[g] = fail(kc, RTW_ERR_OOM, "shard buffer"); return; }
+                kc->out_pix = npix;
+            }
+            rcs[g] = npix ? render_single(kc, &kp[g], kc->d_out, nullptr, &kst[g]) : RTW_OK;
+        });
+    }
+    for (auto& t : th) t.join();
+    for (size_t g = 0; g < n; g++)
+        if (rcs[g] != RTW_OK) return fail(c, rcs[g], std::string("device ") + std::to_string(c->kids[g]->device) + ": " + c->kids[g]->err);
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!s) s = c->stream;
+    const size_t npix = rows * (size_t)P->width;
+    if (npix > c->stage_pix) {
+        if (c->stage) (void)hipFree(c->stage);
+        c->stage = nullptr; c->stage_pix = 0;
+        HIP_TRY(c, hipMalloc(&c->stage, npix * sizeof(float4) + (n + 1) * sizeof(uint32_t) + 256));
+        c->stage_pix = npix;
+    }
+    uint32_t* d_off = (uint32_t*)((char*)c->stage + ((npix * sizeof(float4) + 255) & ~(size_t)255));
+    HIP_TRY(c, hipMemcpyAsync(d_off, off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    for (size_t g = 0; g < n; g++) {  // the gather: one peer copy per shard, all on the group's stream
+        const size_t bytes = krows[g] * (size_t)P->width * sizeof(float4);
+        if (bytes) HIP_TRY(c, hipMemcpyPeerAsync(c->stage + (size_t)off[g] * P->width, c->device, c->kids[g]->d_out, c->kids[g]->device, bytes, s));
+    }
+    hipLaunchKernelGGL(k_interleave, dim3((unsigned)std::min<size_t>((npix + 255) / 256, (size_t)c->n_cu * 8)), dim3(256), 0, s, (const float4*)c->stage,
+                       (float4*)d_rgba, (uint32_t)P->width, (uint32_t)rows, (uint32_t)n, (const uint32_t*)d_off);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(s));
+    if (stats) {
+        for (size_t g = 0; g < n; g++) {
+            stats->samples += kst[g].samples; stats->segments += kst[g].segments; stats->shadow_rays += kst[g].shadow_rays;
+            stats->algorithmic_bytes += kst[g].algorithmic_bytes; stats->bounce_launches += kst[g].bounce_launches;
+            stats->seconds = std::max(stats->seconds, kst[g].seconds);
+            stats->bounce_seconds = std::max(stats->bounce_seconds, kst[g].bounce_seconds);
+            for (int q = 0; q < RTW_K_COUNT; q++) {
+                stats->kernel_seconds[q] += kst[g].kernel_seconds[q]; stats->kernel_launches[q] += kst[g].kernel_launches[q];
+                stats->kernel_segments[q] += kst[g].kernel_segments[q];
+            }
+        }
+    }
+    return RTW_OK;
+}
+
+int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_stream, rtw_stats* stats) {
+    if (!c) return RTW_ERR_INVALID_ARG;
+    int rc = check_render_args(c, P);
+    if (rc) return rc;
+    if (!d_rgba) return fail(c, RTW_ERR_INVALID_ARG, "null params or output");
+    if (!c->kids.empty()) return render_group(c, P, d_rgba, (hipStream_t)hip_stream, stats);
+    return render_single(c, P, d_rgba, (hipStream_t)hip_stream, stats);
 }
 
 int rtw_render(rtw_ctx* c, const rtw_params* P, float* rgba_out, rtw_stats* stats) {
@@ -806,8 +1064,7 @@ int rtw_render(rtw_ctx* c, const rtw_params* P, float* rgba_out, rtw_stats* stat
     if (!rgba_out) return fail(c, RTW_ERR_INVALID_ARG, "null output");
     if (!P) return fail(c, RTW_ERR_INVALID_ARG, "null params");
     if (P->width <= 0 || P->row0 < 0 || P->row1 < P->row0) return fail(c, RTW_ERR_INVALID_ARG, "bad render params");
-    const size_t k_ = P->row_stride > 1 ? (size_t)P->row_stride : 1;
-    const size_t npix = (((size_t)(P->row1 - P->row0) + k_ - 1) / k_) * (size_t)P->width;
+    const size_t npix = shard_rows(P) * (size_t)P->width;
     HIP_TRY(c, hipSetDevice(c->device));
     if (npix > c->out_pix) {
         if (c->d_out) (void)hipFree(c->d_out);

@@ -52,6 +52,10 @@ struct KArgs {
     uint32_t row_stride;        // >= 1: local row l of the shard is image row row0 + l*row_stride
     uint32_t divw_m, divw_s1, divw_s2;  // exact division by width (multiply-high + shifts)
     uint32_t divs_m, divs_s1, divs_s2;  // exact division by row_stride
+    // k_path (register-resident paths with in-wave regeneration)
+    uint32_t* queue;            // [0]: next job of the launch (one returning atomic per job and wave)
+    float4* blocksum;           // [block - block0][shard-local pixel]: sum of the block's samples in sample order
+    uint32_t n_jobs, n_ranges, blocks_per_job, block0, n_blocks_pass, spp;
 };
 
 struct Path {
@@ -170,7 +174,7 @@ struct Nee {
 // TEX: the instantiation for scenes with non-constant textures or media (the cold features)
 template <int KIND, bool TEX>
 RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 dir, const float gather_time, const float t, const int prim,
-                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee, const uint32_t* noise_lds, uint32_t& nee_prev) {
+                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee, const uint32_t* noise_lds, uint32_t& nee_prev, const u32x4* hr_lds = nullptr) {
     // nee_prev (corrected estimator only): in - a light sample was taken at the previous vertex; out - one was taken here
     const int est = TEX ? sc.estimator : 0;
     const uint32_t had_nee = nee_prev;
@@ -190,7 +194,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         return EV_MISS;
     }
     g.align_block();
-    const HitRec hr = load_hitrec(sc, prim);
+    const HitRec hr = load_hitrec(sc, prim, hr_lds);
     if (hr.mat_type != RTW_MAT_DIFFUSE_LIGHT && hr.mat_type != RTW_MAT_NORMAL) g.warm();
     v3 hp, hn;
     hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
@@ -514,6 +518,49 @@ RTW_DEV const uint32_t* stage_noise(const DScene& sc, uint32_t* s_noise) {
     return s_noise;
 }
 
+// __raygen__Program (raygen.cu:123-147) + perspectiveCamera (camera.cu:11-19) + color() (raygen.cu:89-95): the camera
+// path of sample `sample` of image pixel (x, y); shared by k_first and k_path so that both draw the same numbers.
+template <int KIND>
+RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const uint32_t sample, const uint32_t path_id, Path& p, Rng<KIND>& g) {
+    const uint32_t pixel = A.width * y + x;
+    float r0, r1, r2, r3, r4;
+    if (KIND == RTW_RNG_TEA_LCG) {
+        uint32_t s = tea<64>(pixel, sample);  // raygen.cu:129
+        r0 = lcg_rnd(s); r1 = lcg_rnd(s); r2 = lcg_rnd(s); r3 = lcg_rnd(s);
+        g.init(A.seed, pixel, sample, s, s);  // prd.seed = seed; rayColor's local copy (Q7)
+        r4 = lcg_rnd(s);
+        p.w0 = path_id;
+    } else {
+        uint32_t o[4];
+        philox4x32_10(pixel, sample, 0u, 0u, A.seed, 0u, o);
+        r0 = u24(o[0]); r1 = u24(o[1]); r2 = u24(o[2]); r3 = u24(o[3]);
+        // fifth raygen draw (gather time) from the block's spare low bytes: one raygen block per camera path
+        r4 = (float)(((o[0] & 0xffu) << 16) | ((o[1] & 0xffu) << 8) | (o[2] & 0xffu)) * (1.0f / 16777216.0f);
+        g.init(A.seed, pixel, sample, 0u, sample);
+        p.w0 = pixel;
+    }
+    const rtw_camera& cam = A.sc.cam;
+    const float s = ((float)x + r0) / (float)A.width;
+    const float t = ((float)y + r1) / (float)A.height;
+    p.o = ld3(cam.origin);
+    if (cam.lens_radius != 0.0f) {  // sampling.cuh:15-22; the two draws are consumed either way
+        float sn, cs;
+        sincos2pi(r2, sn, cs);
+        float sq = __builtin_sqrtf(r3);
+        float rx = cam.lens_radius * (sn * sq);
+        float ry = cam.lens_radius * (cs * sq);
+        p.o = vadd(p.o, vfma(ld3(cam.v), ry, vscale(ld3(cam.u), rx)));
+    }
+    p.d = vfma(ld3(cam.horizontal), s, ld3(cam.lower_left));
+    p.d = vfma(ld3(cam.vertical), t, p.d);
+    p.d = vsub(p.d, p.o);
+    p.gk = (uint32_t)(r4 * 16777216.0f);
+    p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(0u) : 0.0f;  // raygen.cu:48
+    p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;
+    p.T = V(1.f, 1.f, 1.f); p.L = V(0.f, 0.f, 0.f); p.c = V(0.f, 0.f, 0.f);
+    p.a = g.a; p.b = g.b;
+}
+
 // ------------------------------------------------------------------ k_first
 template <int KIND, bool TEX>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
@@ -532,51 +579,13 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
         Path p;
         p.gk = 0; p.ltmax = -1.f;
         if (path_id < A.n_paths) {
-        // __raygen__Program (raygen.cu:123-147) + perspectiveCamera (camera.cu:11-19) + color() (raygen.cu:89-95)
         const uint32_t slot = path_id / A.npix;
         const uint32_t pl = path_id - slot * A.npix;
         const uint32_t yl = pl / A.width;
         const uint32_t x = pl - yl * A.width;
         const uint32_t y = A.row0 + yl * A.row_stride;
-        const uint32_t pixel = A.width * y + x;
-        const uint32_t sample = A.sample0 + slot;
         Rng<KIND> g;
-        float r0, r1, r2, r3, r4;
-        if (KIND == RTW_RNG_TEA_LCG) {
-            uint32_t s = tea<64>(pixel, sample);  // raygen.cu:129
-            r0 = lcg_rnd(s); r1 = lcg_rnd(s); r2 = lcg_rnd(s); r3 = lcg_rnd(s);
-            g.init(A.seed, pixel, sample, s, s);  // prd.seed = seed; rayColor's local copy (Q7)
-            r4 = lcg_rnd(s);
-            p.w0 = path_id;
-        } else {
-            uint32_t o[4];
-            philox4x32_10(pixel, sample, 0u, 0u, A.seed, 0u, o);
-            r0 = u24(o[0]); r1 = u24(o[1]); r2 = u24(o[2]); r3 = u24(o[3]);
-            // fifth raygen draw (gather time) from the block's spare low bytes: one raygen block per camera path
-            r4 = (float)(((o[0] & 0xffu) << 16) | ((o[1] & 0xffu) << 8) | (o[2] & 0xffu)) * (1.0f / 16777216.0f);
-            g.init(A.seed, pixel, sample, 0u, sample);
-            p.w0 = pixel;
-        }
-        const rtw_camera& cam = A.sc.cam;
-        const float s = ((float)x + r0) / (float)A.width;
-        const float t = ((float)y + r1) / (float)A.height;
-        p.o = ld3(cam.origin);
-        if (cam.lens_radius != 0.0f) {  // sampling.cuh:15-22; the two draws are consumed either way
-            float sn, cs;
-            sincos2pi(r2, sn, cs);
-            float sq = __builtin_sqrtf(r3);
-            float rx = cam.lens_radius * (sn * sq);
-            float ry = cam.lens_radius * (cs * sq);
-            p.o = vadd(p.o, vfma(ld3(cam.v), ry, vscale(ld3(cam.u), rx)));
-        }
-        p.d = vfma(ld3(cam.horizontal), s, ld3(cam.lower_left));
-        p.d = vfma(ld3(cam.vertical), t, p.d);
-        p.d = vsub(p.d, p.o);
-        p.gk = (uint32_t)(r4 * 16777216.0f);
-        p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(0u) : 0.0f;  // raygen.cu:48
-        p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;
-        p.T = V(1.f, 1.f, 1.f); p.L = V(0.f, 0.f, 0.f); p.c = V(0.f, 0.f, 0.f);
-        p.a = g.a; p.b = g.b;
+        raygen<KIND>(A, x, y, A.sample0 + slot, path_id, p, g);
         keep = true;
         if (A.trace_first) {
             // split pipeline: trace and shade the primary segment here (primary rays are coherent, so the fused
@@ -975,6 +984,185 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
     cursor_publish(A, s_cursor, n_seg, n_shadow, RTW_K_BOUNCE);
 }
 
+// ------------------------------------------------------------------ k_path
+// Small scenes (scalar-cache candidate lists): the whole path lives in registers. A lane owns one UNIT at a time - one
+// pixel, one block of kSumBlock consecutive samples - and walks the unit's paths one segment per loop iteration: camera
+// ray when it has none (regeneration), closest hit, closest-hit / miss program, the light sample's shadow probe, roulette.
+// A finished sample is added to the unit's sum in sample order; a finished unit stores its sum and the lane takes the
+// next unit of its wave's stream (ballot + mbcnt ranks, no atomics). A wave's stream is a queue of jobs (64 neighbouring
+// pixels x blocks_per_job blocks), one returning atomic per job, so lanes never wait for each other: every iteration
+// runs with all 64 lanes on live paths until the launch runs dry. Nothing but the 16-byte unit sums reaches HBM.
+// The image does not depend on which lane ran which unit: a unit's sum is a function of (pixel, block) alone, and the
+// per-pixel sums are taken block by block in order (k_resolve_blocks) - the summation order of the arithmetic spec.
+constexpr uint32_t kSumBlock = RTW_SUM_BLOCK;
+constexpr int kPathMaxPrims = 64;  // k_path walks the brute lists only: scenes of at most this many primitives
+// diagnostics (never in the shipped build): RTW_MARKERS leaves "; MARK <phase>" comments in the ISA for per-phase
+// instruction counts; RTW_PHASE_TIMERS accumulates s_memtime deltas per phase and wave (printed by the host)
+#if defined(RTW_PHASE_TIMERS)
+#define RTW_MARK(name) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_cyc[ph_cur] += now_ - ph_t0; ph_t0 = now_; ph_cur = rtw_phase_id(name); }
+RTW_DEV constexpr int rtw_phase_id(const char* n) { return n[0] == 'r' && n[2] == 'f' ? 0 : n[0] == 'r' ? 1 : n[0] == 'w' && n[5] == 'r' ? 2 : n[0] == 's' && n[6] == 'a' ? 3 : n[0] == 'w' ? 4 : 5; }
+#elif defined(RTW_MARKERS)
+#define RTW_MARK(name) asm volatile("; MARK " name)
+#else
+#define RTW_MARK(name)
+#endif
+#ifndef RTW_PATH_WAVES
+#define RTW_PATH_WAVES RTW_MIN_WAVES
+#endif
+template <int KIND, bool TEX>
+__global__ void __launch_bounds__(kBlock, RTW_PATH_WAVES) k_path(const KArgs A) {
+    RTW_NOISE_SHARED
+    __shared__ u32x4 s_hitrec[kPathMaxPrims * 6];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
+    {   // the hit records of a small scene live in LDS for the whole launch
+        const u32x4* src = (const u32x4*)A.sc.hitrec;
+        for (uint32_t i = tid; i < (uint32_t)A.sc.n_prims * 6u; i += kBlock) s_hitrec[i] = src[i];
+    }
+    __shared__ u32x4 s_walk[TEX ? 1 : kWalkMaxWords];
+    if (!TEX) for (uint32_t i = tid; i < (uint32_t)A.sc.n_walk_words; i += kBlock) s_walk[i] = A.sc.walk[i];
+    __syncthreads();
+    const uint32_t lane = tid & 63u;
+    // wave-uniform: the job stream
+    uint32_t u_next = 0, u_end = 0, job_g = 0, job_b = 0;
+    bool exhausted = false;
+    // per lane: the unit
+    bool need = true;
+    uint32_t px = 0, py = 0, pl = 0, blk = 0, s_cur = 0, s_end = 0;
+    v3 usum = V(0.f, 0.f, 0.f);
+    // per lane: the path
+    bool alive = false;
+    uint32_t depth = 0, gk = 0, rng_a = 0, rng_b = 0, nee_prev = 0;
+    float ray_time = 0.f;
+    v3 o = V(0.f, 0.f, 0.f), d = o, T = o, L = o;
+    uint32_t n_seg = 0, n_shadow = 0;
+#ifdef RTW_PHASE_TIMERS
+    unsigned long long ph_cyc[6] = {0, 0, 0, 0, 0, 0}, ph_t0 = __builtin_amdgcn_s_memtime();
+    int ph_cur = 0;
+#endif
+    for (;;) {
+        RTW_MARK("refill");
+        unsigned long long need_mask = __ballot(need);
+        while (need_mask != 0ull && !exhausted) {
+            if (u_next >= u_end) {
+                uint32_t q = 0;
+                if (lane == 0) q = atomicAdd(A.queue, 1u);
+                q = __builtin_amdgcn_readfirstlane(q);
+                if (q >= A.n_jobs) { exhausted = true; break; }
+                job_g = q / A.n_ranges;
+                job_b = (q - job_g * A.n_ranges) * A.blocks_per_job;
+                u_next = 0; u_end = 64u * A.blocks_per_job;
+                continue;
+            }
+            const uint32_t avail = u_end - u_next;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+            if (need && rank < avail) {
+                const uint32_t u = u_next + rank;
+                const uint32_t b = job_b + (u >> 6);
+                const uint32_t p_local = job_g * 64u + (u & 63u);
+                if (p_local < A.npix && b < A.n_blocks_pass) {
+                    need = false;
+                    pl = p_local; blk = b;
+                    const uint32_t yl = fastdiv(p_local, A.divw_m, A.divw_s1, A.divw_s2);
+                    px = p_local - yl * A.width;
+                    py = A.row0 + yl * A.row_stride;
+                    s_cur = (A.block0 + b) * kSumBlock;
+                    s_end = min(s_cur + kSumBlock, A.spp);
+                    usum = V(0.f, 0.f, 0.f);
+                    alive = false;
+                }
+            }
+            u_next += min((uint32_t)__popcll(need_mask), avail);
+            need_mask = __ballot(need);
+        }
+        if (__ballot(!need) == 0ull) break;
+        RTW_MARK("regen");
+        const bool busy = !need;
+        Rng<KIND> g;
+        if (busy && !alive) {  // regeneration: the next camera path of this lane's unit
+            Path p;
+            raygen<KIND>(A, px, py, A.sample0 + s_cur, 0u, p, g);
+            o = p.o; d = p.d; ray_time = p.ray_time; gk = p.gk; T = p.T; L = p.L; rng_a = p.a; rng_b = p.b;
+            depth = 0; nee_prev = 0; alive = true;
+        }
+        if (busy) {
+            const uint32_t pixel = A.width * py + px;
+            if (KIND == RTW_RNG_TEA_LCG) g.init(A.seed, 0, 0, rng_a, rng_b);
+            else g.init(A.seed, pixel, A.sample0 + s_cur, rng_a, rng_b);
+        }
+        RTW_MARK("walk_r");
+        const float gt = gather_time_of(A, gk);
+        // closest hit (raygen.cu:41-54). Camera rays of neighbouring pixels that all look past the scene skip the walk.
+        float th = 1.e27f;
+        int prim = -1;
+        const bool walk = busy && (depth > 0u || may_hit_scene(A.sc, o, d));
+        if (__ballot(walk) != 0ull) {
+            if (busy) {
+                if (TEX) traverse_brute<Rng<KIND>, false, false>(A.sc, o, d, A.sc.ray_tmin, 1.e27f, ray_time, gt, g, th, prim);
+                else walk_lds<false>(s_walk, A.sc.n_groups, o, d, A.sc.ray_tmin, 1.e27f, th, prim);
+            }
+        }
+        RTW_MARK("shade_a");
+        if (busy) {
+            v3 so, sd, att, radiance;
+            Nee nee;
+            const int ev = shade_a<KIND, TEX>(A.sc, g, o, d, gt, th, prim, so, sd, att, radiance, nee, noise_lds, nee_prev, s_hitrec);
+            n_seg++;
+            RTW_MARK("walk_s");
+            if (nee.has) {  // traceOcclusion, closehit.cu:16-42
+                float st;
+                int sprim;
+                if (TEX) traverse_brute<Rng<KIND>, true, false>(A.sc, so, nee.dir, nee.tmin, nee.tmax, 0.0f, gt, g, st, sprim);
+                else walk_lds<true>(s_walk, A.sc.n_groups, so, nee.dir, nee.tmin, nee.tmax, st, sprim);
+                n_shadow++;
+                if (sprim < 0) radiance = vadd(radiance, nee.rad);
+            }
+            RTW_MARK("shade_b");
+            alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L);
+            depth++;
+            rng_a = g.a; rng_b = g.b;
+            if (alive) {
+                ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(depth) : 0.0f;
+                rng_b = g.b;
+            } else {
+                // removeNaNs (raygen.cu:17-24), then the unit's running sum, in sample order
+                usum = vadd(usum, V((L.x == L.x) ? L.x : 0.f, (L.y == L.y) ? L.y : 0.f, (L.z == L.z) ? L.z : 0.f));
+                s_cur++;
+                if (s_cur >= s_end) {
+                    A.blocksum[(size_t)blk * A.npix + pl] = make_float4(usum.x, usum.y, usum.z, 0.f);
+                    need = true;
+                }
+            }
+        }
+    }
+#ifdef RTW_PHASE_TIMERS
+    RTW_MARK("refill");
+    if (lane == 0) for (int q = 0; q < 6; q++) atomicAdd(&A.stats[kStatRows * 8 + q], ph_cyc[q]);
+#endif
+    for (int off = 32; off > 0; off >>= 1) {
+        n_seg += __shfl_down(n_seg, off);
+        n_shadow += __shfl_down(n_shadow, off);
+    }
+    if (lane == 0) {
+        unsigned long long* row = stat_row(A);
+        if (n_seg) { atomicAdd(&row[0], (unsigned long long)n_seg); atomicAdd(&row[2 + RTW_K_PATH], (unsigned long long)n_seg); }
+        if (n_shadow) atomicAdd(&row[1], (unsigned long long)n_shadow);
+    }
+}
+
+// per-pixel sums, block by block in ascending order (the arithmetic spec's summation order: samples are summed in
+// order inside aligned blocks of kSumBlock, the block sums in order)
+__global__ void __launch_bounds__(kBlock) k_resolve_blocks(const float4* __restrict__ blocksum, float4* __restrict__ accum, uint32_t npix, uint32_t nblocks) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
+        float4 a = accum[i];
+        for (uint32_t b = 0; b < nblocks; b++) {
+            const float4 l = blocksum[(size_t)b * npix + i];
+            a.x += l.x; a.y += l.y; a.z += l.z;
+        }
+        accum[i] = a;
+    }
+}
+
 // One a-trous pass (rtw.h rtw_denoise): 25 taps in row-major order, clamped at the borders, plain fp32 in a fixed order
 __global__ void __launch_bounds__(kBlock) k_atrous(const float4* __restrict__ in, float4* __restrict__ out, int width, int height, int step, float inv_sigma2) {
     const int n = width * height;
@@ -1000,21 +1188,32 @@ __global__ void __launch_bounds__(kBlock) k_atrous(const float4* __restrict__ in
     }
 }
 
-// sums the S sample slots of every pixel in ascending sample order (fixed order => reproducible bits)
-__global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ lbuf, float4* __restrict__ accum, uint32_t npix, uint32_t nslots) {
+// Sums the S sample slots of every pixel in the arithmetic spec's order (rtw.h RTW_SUM_BLOCK): slot s is sample
+// first_sample + s of the render call; samples add up in order inside aligned blocks of kSumBlock (running block sum in
+// `part`), a finished block's sum is added to `accum`. Fixed order => reproducible bits, whatever the batch size.
+__global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ lbuf, float4* __restrict__ accum, float4* __restrict__ part, uint32_t npix,
+                                                    uint32_t nslots, uint32_t first_sample) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        float4 a = accum[i];
+        float4 a = accum[i], b = part[i];
         for (uint32_t s = 0; s < nslots; s++) {
+            const uint32_t rel = first_sample + s;
+            if (rel != 0u && (rel % kSumBlock) == 0u) {
+                a.x += b.x; a.y += b.y; a.z += b.z;
+                b = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
             float4 l = lbuf[(size_t)s * npix + i];
-            a.x += l.x; a.y += l.y; a.z += l.z;
+            b.x += l.x; b.y += l.y; b.z += l.z;
         }
         accum[i] = a;
+        part[i] = b;
     }
 }
 
-__global__ void __launch_bounds__(kBlock) k_finish(const float4* __restrict__ accum, float4* __restrict__ out, uint32_t npix, float spp) {
+// mean radiance: the last (possibly partial) block's sum joins the total, then the division by spp
+__global__ void __launch_bounds__(kBlock) k_finish(const float4* __restrict__ accum, const float4* __restrict__ part, float4* __restrict__ out, uint32_t npix, float spp) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
         float4 a = accum[i];
+        if (part != nullptr) { const float4 b = part[i]; a.x += b.x; a.y += b.y; a.z += b.z; }
         out[i] = make_float4(a.x / spp, a.y / spp, a.z / spp, 1.0f);
     }
 }

@@ -57,7 +57,7 @@ inline std::vector<uint8_t> marshalScene(const ioScene& sc) {
 
     rtw_scene_header h{};
     h.magic = RTW_SCENE_MAGIC;
-    h.version = RTW_ABI_VERSION;
+    h.version = RTW_SCENE_VERSION;
     h.n_prims = static_cast<uint32_t>(prims.size());
     h.n_xforms = static_cast<uint32_t>(xforms.size());
     h.n_materials = static_cast<uint32_t>(mats.size());

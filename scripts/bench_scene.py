@@ -7,7 +7,8 @@ scene, w, h, spp, depth = (int(x) for x in sys.argv[1:6])
 rng = int(sys.argv[6]) if len(sys.argv) > 6 else 0
 r = abi.Renderer(0); r.upload_scene(abi.build_scene(scene, w, h))
 r.render(abi.make_params(w, h, min(spp, 8), depth, rng_kind=rng))
-_, st = r.render(abi.make_params(w, h, spp, depth, rng_kind=rng))
-print(json.dumps({"scene": scene, "Msamples_per_s": round(st.samples / st.seconds / 1e6, 1), "seconds": round(st.seconds, 4),
+img, st = r.render(abi.make_params(w, h, spp, depth, rng_kind=rng))
+import zlib
+print(json.dumps({"lib": os.path.basename(abi.HIP_LIB), "crc": zlib.crc32(img.tobytes()), "scene": scene, "Msamples_per_s": round(st.samples / st.seconds / 1e6, 1), "seconds": round(st.seconds, 4),
                   "seg_per_sample": round(st.segments / st.samples, 3),
                   "kernels": {n: {"s": round(st.kernel_seconds[i], 4), "launches": st.kernel_launches[i], "units": st.kernel_segments[i]} for i, n in enumerate(abi.Stats.KERNELS)}}))

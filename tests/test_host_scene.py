@@ -16,13 +16,13 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def test_struct_sizes_match_header():
     assert C.sizeof(abi.Prim) == 64 and C.sizeof(abi.Xform) == 96 and C.sizeof(abi.Material) == 16
     assert C.sizeof(abi.Texture) == 32 and C.sizeof(abi.Light) == 64 and C.sizeof(abi.Pdf) == 48
-    assert C.sizeof(abi.Camera) == 96 and C.sizeof(abi.Params) == 48 and C.sizeof(abi.Stats) == 160
+    assert C.sizeof(abi.Camera) == 96 and C.sizeof(abi.Params) == 48 and C.sizeof(abi.Stats) == 184
 
 
 def test_cornell_box_blob():
     s = abi.parse_scene(abi.build_scene(0, 800, 800))
     h = s["header"]
-    assert (h.magic, h.version) == (abi.RTW_SCENE_MAGIC, abi.RTW_ABI_VERSION)
+    assert (h.magic, h.version) == (abi.RTW_SCENE_MAGIC, abi.RTW_SCENE_VERSION)
     assert (h.n_prims, h.n_materials, h.n_lights, h.sky_light, h.n_xforms) == (13, 13, 1, 0, 2)  # ioScene.h:491-627
     prims = s["prims"]
     assert prims[0].type == abi.PRIM_SPHERE and list(prims[0].p[:4]) == [190.0, 90.0, 190.0, 90.0]

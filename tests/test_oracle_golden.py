@@ -110,7 +110,7 @@ def test_invalid_inputs_are_rejected():
 def one_prim_scene(prim):
     """A blob with a single primitive, identity transform, one lambertian material."""
     hdr = abi.SceneHeader()
-    hdr.magic, hdr.version = abi.RTW_SCENE_MAGIC, abi.RTW_ABI_VERSION
+    hdr.magic, hdr.version = abi.RTW_SCENE_MAGIC, abi.RTW_SCENE_VERSION
     hdr.n_prims = hdr.n_xforms = hdr.n_materials = hdr.n_textures = 1
     sizes = [C.sizeof(abi.SceneHeader), 64, 96, 16, 32]
     offs = [0]
