@@ -1026,13 +1026,15 @@ __global__ void __launch_bounds__(kBlock, RTW_PATH_WAVES) k_path(const KArgs A) 
     // wave-uniform: the job stream
     uint32_t u_next = 0, u_end = 0, job_g = 0, job_b = 0;
     bool exhausted = false;
-    // per lane: the unit
+    // per lane, the unit: pixel (x | y << 16 of the full image), block of the pass, current sample (relative to sample_offset)
     bool need = true;
-    uint32_t px = 0, py = 0, pl = 0, blk = 0, s_cur = 0, s_end = 0;
+    uint32_t pxy = 0, blk = 0, s_cur = 0;
     v3 usum = V(0.f, 0.f, 0.f);
-    // per lane: the path
+    // per lane, the path. The instantiation without the cold features (TEX == false) has no motion, no media and the
+    // reference estimator: ray time, gather time and the ray-time stream are dead there and take no registers.
     bool alive = false;
-    uint32_t depth = 0, gk = 0, rng_a = 0, rng_b = 0, nee_prev = 0;
+    uint32_t depth = 0, rng_a = 0;
+    uint32_t gk = 0, rng_b = 0, nee_prev = 0;
     float ray_time = 0.f;
     v3 o = V(0.f, 0.f, 0.f), d = o, T = o, L = o;
     uint32_t n_seg = 0, n_shadow = 0;
@@ -1062,12 +1064,10 @@ __global__ void __launch_bounds__(kBlock, RTW_PATH_WAVES) k_path(const KArgs A) 
                 const uint32_t p_local = job_g * 64u + (u & 63u);
                 if (p_local < A.npix && b < A.n_blocks_pass) {
                     need = false;
-                    pl = p_local; blk = b;
+                    blk = b;
                     const uint32_t yl = fastdiv(p_local, A.divw_m, A.divw_s1, A.divw_s2);
-                    px = p_local - yl * A.width;
-                    py = A.row0 + yl * A.row_stride;
+                    pxy = (p_local - yl * A.width) | ((A.row0 + yl * A.row_stride) << 16);
                     s_cur = (A.block0 + b) * kSumBlock;
-                    s_end = min(s_cur + kSumBlock, A.spp);
                     usum = V(0.f, 0.f, 0.f);
                     alive = false;
                 }
@@ -1078,20 +1078,22 @@ __global__ void __launch_bounds__(kBlock, RTW_PATH_WAVES) k_path(const KArgs A) 
         if (__ballot(!need) == 0ull) break;
         RTW_MARK("regen");
         const bool busy = !need;
+        const uint32_t px = pxy & 0xffffu, py = pxy >> 16;
         Rng<KIND> g;
         if (busy && !alive) {  // regeneration: the next camera path of this lane's unit
             Path p;
             raygen<KIND>(A, px, py, A.sample0 + s_cur, 0u, p, g);
-            o = p.o; d = p.d; ray_time = p.ray_time; gk = p.gk; T = p.T; L = p.L; rng_a = p.a; rng_b = p.b;
-            depth = 0; nee_prev = 0; alive = true;
+            o = p.o; d = p.d; T = p.T; L = p.L; rng_a = p.a;
+            if (TEX) { ray_time = p.ray_time; gk = p.gk; rng_b = p.b; nee_prev = 0; }
+            depth = 0; alive = true;
         }
         if (busy) {
             const uint32_t pixel = A.width * py + px;
             if (KIND == RTW_RNG_TEA_LCG) g.init(A.seed, 0, 0, rng_a, rng_b);
-            else g.init(A.seed, pixel, A.sample0 + s_cur, rng_a, rng_b);
+            else g.init(A.seed, pixel, A.sample0 + s_cur, rng_a, A.sample0 + s_cur);
         }
         RTW_MARK("walk_r");
-        const float gt = gather_time_of(A, gk);
+        const float gt = TEX ? gather_time_of(A, gk) : 0.0f;
         // closest hit (raygen.cu:41-54). Camera rays of neighbouring pixels that all look past the scene skip the walk.
         float th = 1.e27f;
         int prim = -1;
@@ -1120,16 +1122,19 @@ __global__ void __launch_bounds__(kBlock, RTW_PATH_WAVES) k_path(const KArgs A) 
             RTW_MARK("shade_b");
             alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L);
             depth++;
-            rng_a = g.a; rng_b = g.b;
+            rng_a = g.a;
             if (alive) {
-                ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(depth) : 0.0f;
-                rng_b = g.b;
+                if (TEX) {
+                    ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(depth) : 0.0f;
+                    rng_b = g.b;
+                }
             } else {
                 // removeNaNs (raygen.cu:17-24), then the unit's running sum, in sample order
                 usum = vadd(usum, V((L.x == L.x) ? L.x : 0.f, (L.y == L.y) ? L.y : 0.f, (L.z == L.z) ? L.z : 0.f));
                 s_cur++;
-                if (s_cur >= s_end) {
-                    A.blocksum[(size_t)blk * A.npix + pl] = make_float4(usum.x, usum.y, usum.z, 0.f);
+                if ((s_cur % kSumBlock) == 0u || s_cur >= A.spp) {
+                    const uint32_t yl_ = A.row_stride > 1 ? fastdiv(py - A.row0, A.divs_m, A.divs_s1, A.divs_s2) : py - A.row0;
+                    A.blocksum[(size_t)blk * A.npix + (yl_ * A.width + px)] = make_float4(usum.x, usum.y, usum.z, 0.f);
                     need = true;
                 }
             }
