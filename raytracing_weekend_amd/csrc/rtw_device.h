@@ -404,6 +404,10 @@ RTW_DEV BruteRec load_rec(const DScene& sc, int i) {
     r.e = __uint_as_float(q[4]); r.prim = (int)q[5]; r.pad0 = 0; r.pad1 = 0;
     return r;
 }
+#ifndef RTW_LDS_NODE_VECS
+#define RTW_LDS_NODE_VECS 5
+#endif
+constexpr int kLdsNodeVecs = RTW_LDS_NODE_VECS;  // 16-byte vectors per tree node in the LDS copy (4 = packed)
 // Per-thread traversal memory: this thread's column of the LDS stack and the block's LDS copy of the top of the tree.
 struct TravMem {
     uint32_t* stack;
@@ -421,8 +425,11 @@ RTW_DEV TravMem trav_mem(const DScene& sc, uint32_t* lds, uint32_t block, uint32
     tm.nodes = cache;
     tm.n_nodes = (uint32_t)sc.n_lds_nodes;
     if (tm.n_nodes) {
+        // LDS copy with a stride of kLdsNodeVecs 16-byte vectors per node: at the natural stride of 4 (64 B) the four
+        // ds_read_b128 of a node fall on only four bank groups, whatever the node (a 4-way conflict for 16 lanes at 16
+        // different nodes); 5 (80 B) spreads consecutive nodes over all sixteen 4-bank groups
         const u32x4* src = (const u32x4*)sc.nodes;
-        for (uint32_t i = tid; i < tm.n_nodes * 4u; i += block) cache[i] = src[i];
+        for (uint32_t i = tid; i < tm.n_nodes * 4u; i += block) cache[(i >> 2) * kLdsNodeVecs + (i & 3u)] = src[i];
         __syncthreads();
     }
     return tm;
@@ -431,7 +438,7 @@ RTW_DEV TravMem trav_mem(const DScene& sc, uint32_t* lds, uint32_t block, uint32
 RTW_DEV BvhNode load_node(const DScene& sc, const TravMem& tm, uint32_t i) {
     u32x4 a, b, c, d;
     if (i < tm.n_nodes) {
-        const u32x4* q = tm.nodes + 4u * i;
+        const u32x4* q = tm.nodes + (uint32_t)kLdsNodeVecs * i;
         a = q[0]; b = q[1]; c = q[2]; d = q[3];
     } else {
         const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + i);

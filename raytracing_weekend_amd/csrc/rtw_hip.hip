@@ -186,6 +186,8 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_STAGGER     size of the second lane's first batch in percent of a full batch (default 50; 0 = no offset)
 //   RTW_PATH        1 (default): scenes walked with the brute lists render through k_path (paths in registers, in-wave
 //                   regeneration); 0: always the wavefront pipeline
+//   RTW_PATH_TREE   1: tree scenes render through k_path_tree (k_path's idea with a per-lane walk state machine and a vote on the
+//                   kind of step; bit-identical, measured 25-45 % slower than the wavefront kernels on scenes 1, 2, 4); 0 (default): wavefront
 //   RTW_PATH_JOB_BLOCKS  sample blocks per k_path job (default 2: a job is 64 pixels x 128 samples)
 //   RTW_PATH_GRID_MULT   k_path workgroups per CU (default: what the occupancy query admits)
 //   RTW_BLOCKSUM_BYTES   cap of the k_path block-sum buffer (default 16 GiB); larger renders run in passes over the samples
@@ -202,6 +204,7 @@ struct Tuning {
     int stagger_pct = 50;
     int tail_group = 2;
     int path = 1;
+    int path_tree = 0;
     int path_job_blocks = 2;
     int path_grid_mult = 0;
     size_t blocksum_bytes = (size_t)16 << 30;
@@ -227,6 +230,7 @@ Tuning read_tuning() {
     if (geti("RTW_TAIL_GROUP", v)) t.tail_group = (int)std::max<long long>(1, std::min<long long>(64, v));
     if (geti("RTW_STAGGER", v)) t.stagger_pct = (int)std::max<long long>(0, std::min<long long>(99, v));
     if (geti("RTW_PATH", v)) t.path = (int)std::max<long long>(0, std::min<long long>(2, v));
+    if (geti("RTW_PATH_TREE", v)) t.path_tree = v != 0;
     if (geti("RTW_PATH_JOB_BLOCKS", v)) t.path_job_blocks = (int)std::max<long long>(1, std::min<long long>(1024, v));
     if (geti("RTW_PATH_GRID_MULT", v)) t.path_grid_mult = (int)std::max<long long>(1, std::min<long long>(16, v));
     if (geti("RTW_BLOCKSUM_BYTES", v) && v >= (1 << 16)) t.blocksum_bytes = (size_t)v;
@@ -234,7 +238,7 @@ Tuning read_tuning() {
     return t;
 }
 
-enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE, LK_PATH = RTW_K_PATH };
+enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE, LK_PATH = RTW_K_PATH, LK_PATH_TREE = RTW_K_COUNT };
 void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s) {
     const bool lcg = rng_kind == RTW_RNG_TEA_LCG;
     // kernels that shade exist in four instantiations: RNG kind x "some material has a non-constant texture"
@@ -255,6 +259,7 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
         else hipLaunchKernelGGL((k_trace<false>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
     case LK_PATH: RTW_LAUNCH_SHADING(k_path, lds); break;
+    case LK_PATH_TREE: RTW_LAUNCH_SHADING(k_path_tree, lds); break;
     default: RTW_LAUNCH_SHADING(k_bounce, lds); break;
 #undef RTW_LAUNCH_SHADING
     }
@@ -640,9 +645,9 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         const size_t budget_kb = tune.lds_kb;
         const size_t stack_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
         const size_t room = budget_kb * 1024 > stack_bytes ? budget_kb * 1024 - stack_bytes : 0;
-        sc.n_lds_nodes = (int32_t)std::min<size_t>(bvh.wide.size(), room / sizeof(BvhNode));
+        sc.n_lds_nodes = (int32_t)std::min<size_t>(bvh.wide.size(), room / ((size_t)kLdsNodeVecs * 16));
     }
-    c->lds_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t) + (size_t)sc.n_lds_nodes * sizeof(BvhNode);
+    c->lds_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t) + (size_t)sc.n_lds_nodes * (size_t)kLdsNodeVecs * 16;
     c->sc = sc;
     c->has_scene = true;
     return RTW_OK;
@@ -697,7 +702,7 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
             launch(kind, P->rng_kind, ka, grid_, lds_, ls);
             return hipSuccess;
         }
-        Timed t{kind, nullptr, nullptr};
+        Timed t{kind == LK_PATH_TREE ? (int)RTW_K_PATH : kind, nullptr, nullptr};
         hipError_t er = new_event(t.a);
         if (er == hipSuccess) er = new_event(t.b);
         if (er == hipSuccess) er = hipEventRecord(t.a, ls);
@@ -732,7 +737,9 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
     const size_t lds = c->lds_bytes;
     const unsigned pix_grid = (unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, (size_t)c->n_cu * 8);
     uint64_t launches = 0;
-    const bool use_path = P->max_depth > 0 && tune.path != 0 && !c->sc.use_bvh && c->sc.n_prims <= kPathMaxPrims && (c->sc.n_walk_words > 0 || c->sc.has_tex);
+    const bool path_small = !c->sc.use_bvh && c->sc.n_prims <= kPathMaxPrims && (c->sc.n_walk_words > 0 || c->sc.has_tex);
+    const bool path_tree = c->sc.use_bvh && tune.path_tree != 0;
+    const bool use_path = P->max_depth > 0 && tune.path != 0 && (path_small || path_tree);
 
     if (use_path) {
         // ---- k_path: paths in registers, lanes regenerate; only the unit sums (16 B per pixel and 64 samples) reach HBM
@@ -747,13 +754,17 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
             c->blocksum_elems = pass_blocks * npix;
         }
         int wg_per_cu = tune.path_grid_mult;
+        const size_t path_lds = path_tree ? lds : 0;
         if (wg_per_cu <= 0) {
             const bool lcg = P->rng_kind == RTW_RNG_TEA_LCG, tex = base.sc.has_tex != 0;
             int nb = 0;
-            hipError_t qe = lcg ? (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_TEA_LCG, true>, kBlock, 0)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_TEA_LCG, false>, kBlock, 0))
-                                : (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_PHILOX, true>, kBlock, 0)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_PHILOX, false>, kBlock, 0));
+            hipError_t qe;
+#define RTW_OCC(K_) (lcg ? (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<RTW_RNG_TEA_LCG, true>, kBlock, path_lds)   \
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<RTW_RNG_TEA_LCG, false>, kBlock, path_lds)) \
+                         : (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<RTW_RNG_PHILOX, true>, kBlock, path_lds)    \
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<RTW_RNG_PHILOX, false>, kBlock, path_lds)))
+            if (path_tree) qe = RTW_OCC(k_path_tree); else qe = RTW_OCC(k_path);
+#undef RTW_OCC
             wg_per_cu = (qe == hipSuccess && nb > 0) ? std::min(nb, 8) : 4;
         }
         HIP_TRY_C(hipEventRecord(ev_begin, s));
@@ -775,7 +786,7 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
             a.block0 = (uint32_t)b0; a.n_blocks_pass = (uint32_t)nb;
             HIP_TRY_C(hipMemsetAsync(c->d_queue, 0, 64, s));
             const int grid = (int)std::min<size_t>((size_t)c->n_cu * (size_t)wg_per_cu, (n_jobs + 3) / 4);
-            HIP_TRY_C(timed_launch(s, LK_PATH, a, grid, 0));
+            HIP_TRY_C(timed_launch(s, path_tree ? LK_PATH_TREE : LK_PATH, a, grid, path_lds));
             launches++;
             hipLaunchKernelGGL(k_resolve_blocks, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->blocksum, c->accum, (uint32_t)npix, (uint32_t)nb);
         }
@@ -939,6 +950,8 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         fprintf(stderr, "[rtw] k_path wave-cycles by phase:");
         for (int q = 0; q < 6; q++) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * (double)ph[q] / tot);
         fprintf(stderr, " (total %.3g wave-cycles, %.0f per 64 segments)\n", tot, tot / ((double)hs[0] / 64.0));
+        if (path_tree) fprintf(stderr, "[rtw] k_path_tree wave steps per 64 segments: inner %.1f  leaf %.1f  shade %.2f\n", (double)ph[6] / ((double)hs[0] / 64.0),
+                               (double)(ph[7] % 1000000ull) / ((double)hs[0] / 64.0), (double)(ph[7] / 1000000ull) / ((double)hs[0] / 64.0));
     }
 #endif
 #ifdef RTW_TRACE_COUNT

@@ -1155,6 +1155,255 @@ __global__ void __launch_bounds__(kBlock, RTW_PATH_WAVES) k_path(const KArgs A) 
     }
 }
 
+// ------------------------------------------------------------------ k_path_tree
+// Tree scenes, same idea as k_path (paths in registers, lanes own units of one pixel x one sample block and regenerate,
+// only the unit sums reach HBM), but a ray's walk through the BVH takes a different number of steps in every lane, so a
+// lane is a small state machine and the wave executes ONE kind of step at a time, chosen by vote:
+//   inner step   lanes standing at an inner node test its two children (bvh_inner_step, LDS stack column per lane)
+//   leaf step    lanes standing at a leaf test one of its primitives
+//   shade step   lanes whose radiance ray has come back run the closest-hit / miss program, roulette, and - when the
+//                sample ends - add it to the unit and start the next camera path; it is the expensive step, so it waits
+//                until RTW_TREE_SHADE_AT lanes want it (or nobody can do anything else)
+// A path alternates: [shadow probe of the previous vertex, if a light sample is pending] -> radiance ray -> shade.
+// The probe's contribution c = f * Le * w * T is held in registers and added to L when the probe comes back free: the
+// same floating-point order as the wavefront kernels (and the oracle). Media are tested in the shade step, where the
+// generator is, exactly as k_shade does.
+#ifndef RTW_TREE_SHADE_AT
+#define RTW_TREE_SHADE_AT 40
+#endif
+#ifndef RTW_TREE_WAVES
+#define RTW_TREE_WAVES RTW_MIN_WAVES
+#endif
+template <int KIND, bool TEX>
+__global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArgs A) {
+    extern __shared__ uint32_t s_stack[];
+    RTW_NOISE_SHARED
+    const uint32_t tid = threadIdx.x;
+    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
+    const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
+    const uint32_t lane = tid & 63u;
+    const uint32_t root = A.sc.n_tree > 0 ? 0u : kBvhDone;
+    // wave-uniform: the job stream
+    uint32_t u_next = 0, u_end = 0, job_g = 0, job_b = 0;
+    bool exhausted = false;
+    // per lane: the unit
+    bool need = true;
+    uint32_t pxy = 0, blk = 0, s_cur = 0;
+    v3 usum = V(0.f, 0.f, 0.f);
+    // per lane: the path
+    enum { PH_SHADE = 0, PH_PROBE = 1, PH_RAY = 2 };  // what the lane waits for: the shade step, or its walk (probe / radiance ray)
+    uint32_t phase = PH_SHADE;
+    bool alive = false;      // false in PH_SHADE: the sample is over (or none was started): finish it and regenerate
+    bool fresh = true;       // no sample to finish (a new unit)
+    uint32_t depth = 0, rng_a = 0, rng_b = 0, gk = 0, nee_prev = 0;
+    float ray_time = 0.f;
+    v3 o = V(0.f, 0.f, 0.f), d = o, T = o, L = o;
+    v3 ldir = o, c = o;      // pending light sample: probe direction, contribution
+    float ltmax = -1.f;
+    // per lane: the walk
+    uint32_t cur = kBvhDone;
+    int sp = 0, best_prim = -1;
+    float best_t = 0.f, tmin = 0.f, wtime = 0.f;
+    v3 wd = o, inv = o;
+    NoRng ng;
+    uint32_t n_seg = 0, n_shadow = 0;
+#ifdef RTW_PHASE_TIMERS
+    unsigned long long ph_cyc[6] = {0, 0, 0, 0, 0, 0}, ph_t0 = __builtin_amdgcn_s_memtime();
+    int ph_cur = 0;
+    unsigned long long st_cnt[3] = {0, 0, 0};
+#endif
+    for (;;) {
+        RTW_MARK("refill");
+        // ---- units
+        unsigned long long need_mask = __ballot(need);
+        while (need_mask != 0ull && !exhausted) {
+            if (u_next >= u_end) {
+                uint32_t q = 0;
+                if (lane == 0) q = atomicAdd(A.queue, 1u);
+                q = __builtin_amdgcn_readfirstlane(q);
+                if (q >= A.n_jobs) { exhausted = true; break; }
+                job_g = q / A.n_ranges;
+                job_b = (q - job_g * A.n_ranges) * A.blocks_per_job;
+                u_next = 0; u_end = 64u * A.blocks_per_job;
+                continue;
+            }
+            const uint32_t avail = u_end - u_next;
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
+            if (need && rank < avail) {
+                const uint32_t u = u_next + rank;
+                const uint32_t b = job_b + (u >> 6);
+                const uint32_t p_local = job_g * 64u + (u & 63u);
+                if (p_local < A.npix && b < A.n_blocks_pass) {
+                    need = false;
+                    blk = b;
+                    const uint32_t yl = fastdiv(p_local, A.divw_m, A.divw_s1, A.divw_s2);
+                    pxy = (p_local - yl * A.width) | ((A.row0 + yl * A.row_stride) << 16);
+                    s_cur = (A.block0 + b) * kSumBlock;
+                    usum = V(0.f, 0.f, 0.f);
+                    phase = PH_SHADE; alive = false; fresh = true;
+                }
+            }
+            u_next += min((uint32_t)__popcll(need_mask), avail);
+            need_mask = __ballot(need);
+        }
+        const unsigned long long busy_mask = __ballot(!need);
+        if (busy_mask == 0ull) break;
+        const bool busy = !need;
+        // ---- vote
+        const bool want_shade = busy && phase == PH_SHADE;
+        const uint32_t n_busy = (uint32_t)__popcll(busy_mask);
+        const uint32_t n_shade = (uint32_t)__popcll(__ballot(want_shade));
+        if (n_shade >= (uint32_t)RTW_TREE_SHADE_AT || n_shade == n_busy) {
+            // ---- shade step
+            RTW_MARK("shade_a");
+#ifdef RTW_PHASE_TIMERS
+            st_cnt[0]++;
+#endif
+            if (want_shade) {
+                const uint32_t px = pxy & 0xffffu, py = pxy >> 16;
+                const uint32_t pixel = A.width * py + px;
+                Rng<KIND> g;
+                if (alive) {
+                    if (KIND == RTW_RNG_TEA_LCG) g.init(A.seed, 0, 0, rng_a, rng_b);
+                    else g.init(A.seed, pixel, A.sample0 + s_cur, rng_a, A.sample0 + s_cur);
+                    const float gt = gather_time_of(A, gk);
+                    int prim = best_prim;
+                    float th = best_t;
+                    if (TEX && A.sc.n_vol > 0) {  // media: tested here, before this segment's closest-hit draws (see k_shade)
+                        float tv = 1.e27f;
+                        int pv = -1;
+                        if (volume_pass<Rng<KIND>, false>(A.sc, o, d, A.sc.ray_tmin, ray_time, gt, g, tv, pv) && !(prim >= 0 && th < tv)) { th = tv; prim = pv; }
+                    }
+                    v3 so, sd, att, radiance;
+                    Nee nee;
+                    const int ev = shade_a<KIND, TEX>(A.sc, g, o, d, gt, th, prim, so, sd, att, radiance, nee, noise_lds, nee_prev);
+                    n_seg++;
+                    ltmax = -1.0f;
+                    if (nee.has) {
+                        n_shadow++;
+                        bool fogged = false;
+                        if (TEX && A.sc.n_vol > 0) {  // the probe's volume share (any hit), right after the light-sample draws
+                            float tv = nee.tmax;
+                            int pv = -1;
+                            fogged = volume_pass<Rng<KIND>, true>(A.sc, so, nee.dir, nee.tmin, 0.0f, gt, g, tv, pv);
+                        }
+                        if (!fogged) { ldir = nee.dir; ltmax = nee.tmax; c = vmul(nee.rad, T); }
+                    }
+                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L);
+                    if (ev == EV_HIT) o = so;  // a pending probe starts at the hit point even when the path stops here
+                    depth++;
+                    rng_a = g.a; rng_b = g.b;
+                    if (alive) {
+                        ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(depth) : 0.0f;
+                        rng_b = g.b;
+                    }
+                    fresh = false;
+                    if (ltmax >= 0.0f) phase = PH_PROBE;        // (a dead path with a probe pending comes back here once it is traced)
+                    else if (alive) phase = PH_RAY;
+                }
+                if (phase == PH_SHADE) {
+                    // the sample is over (or the unit is new): removeNaNs (raygen.cu:17-24), the unit's running sum, the next camera path
+                    if (!fresh) {
+                        usum = vadd(usum, V((L.x == L.x) ? L.x : 0.f, (L.y == L.y) ? L.y : 0.f, (L.z == L.z) ? L.z : 0.f));
+                        s_cur++;
+                        if ((s_cur % kSumBlock) == 0u || s_cur >= A.spp) {
+                            const uint32_t yl_ = A.row_stride > 1 ? fastdiv(py - A.row0, A.divs_m, A.divs_s1, A.divs_s2) : py - A.row0;
+                            A.blocksum[(size_t)blk * A.npix + (yl_ * A.width + px)] = make_float4(usum.x, usum.y, usum.z, 0.f);
+                            need = true;
+                        }
+                    }
+                    if (!need) {
+                        Path p;
+                        raygen<KIND>(A, px, py, A.sample0 + s_cur, 0u, p, g);
+                        o = p.o; d = p.d; T = p.T; L = p.L; rng_a = p.a; rng_b = p.b; ray_time = p.ray_time; gk = p.gk;
+                        depth = 0; nee_prev = 0; alive = true; fresh = false; ltmax = -1.0f;
+                        phase = PH_RAY;
+                    }
+                }
+                // start the walk the lane now waits for
+                if (!need) {
+                    if (phase == PH_PROBE) { wd = ldir; tmin = A.sc.probe_eps; best_t = ltmax; wtime = 0.0f; }
+                    else { wd = d; tmin = A.sc.ray_tmin; best_t = 1.e27f; wtime = ray_time; }
+                    inv = recip3(wd);
+                    best_prim = -1; sp = 0; cur = root;
+                }
+            }
+            continue;
+        }
+        // ---- walk step: inner nodes while the lanes standing at one are not outnumbered, then one leaf primitive
+        RTW_MARK("walk_r");
+        const bool walking = busy && phase != PH_SHADE;
+        const uint32_t n_walk = n_busy - n_shade;
+        bool at_inner = walking && (cur >> 30) == 0u;
+        for (;;) {
+            const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
+            if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_walk - n_in) break;
+            if (at_inner) {
+                cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
+                at_inner = (cur >> 30) == 0u;
+            }
+#ifdef RTW_PHASE_TIMERS
+            st_cnt[1]++;
+#endif
+        }
+#ifdef RTW_PHASE_TIMERS
+        st_cnt[2]++;
+#endif
+        RTW_MARK("walk_s");
+        const bool at_leaf = walking && !at_inner && cur != kBvhDone;
+        if (at_leaf) {
+            const uint32_t first = cur & 0x3fffffffu, cnt = cur >> 30;
+            const int pi = load_i32(A.sc.tree_prims + first);
+            const rtw_prim pr = load_prim(A.sc, pi);
+            v3 po, pd, mt;
+            object_ray(A.sc, pr, o, wd, wtime, po, pd, mt);
+            v3 pinv = inv;
+            if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
+            float t;
+            bool stop = false;
+            if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time_of(A, gk), ng, t)) {
+                // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
+                if (t < best_t || (phase == PH_RAY && t == best_t && best_prim >= 0 && pi < best_prim)) {
+                    best_t = t; best_prim = pi;
+                    stop = phase == PH_PROBE;
+                }
+            }
+            cur = stop ? kBvhDone : (cnt > 1u ? ((first + 1u) | ((cnt - 1u) << 30)) : bvh_pop(tm, sp));
+        }
+        RTW_MARK("shade_b");
+        if (walking && cur == kBvhDone) {
+            if (phase == PH_PROBE) {
+                // traceOcclusion (closehit.cu:16-42) is back: a free path to the light adds the held contribution
+                if (best_prim < 0) L = vadd(L, c);
+                ltmax = -1.0f;
+                if (alive) {
+                    phase = PH_RAY;
+                    wd = d; tmin = A.sc.ray_tmin; best_t = 1.e27f; wtime = ray_time;
+                    inv = recip3(wd);
+                    best_prim = -1; sp = 0; cur = root;
+                } else {
+                    phase = PH_SHADE;  // the path ended at that vertex: finish the sample
+                }
+            } else {
+                phase = PH_SHADE;      // best_t / best_prim hold the closest hit
+            }
+        }
+    }
+#ifdef RTW_PHASE_TIMERS
+    RTW_MARK("refill");
+    if (lane == 0) { for (int q = 0; q < 6; q++) atomicAdd(&A.stats[kStatRows * 8 + q], ph_cyc[q]); atomicAdd(&A.stats[kStatRows * 8 + 6], st_cnt[1]); atomicAdd(&A.stats[kStatRows * 8 + 7], st_cnt[0] * 1000000ull + st_cnt[2]); }
+#endif
+    for (int off = 32; off > 0; off >>= 1) {
+        n_seg += __shfl_down(n_seg, off);
+        n_shadow += __shfl_down(n_shadow, off);
+    }
+    if (lane == 0) {
+        unsigned long long* row = stat_row(A);
+        if (n_seg) { atomicAdd(&row[0], (unsigned long long)n_seg); atomicAdd(&row[2 + RTW_K_PATH], (unsigned long long)n_seg); }
+        if (n_shadow) atomicAdd(&row[1], (unsigned long long)n_shadow);
+    }
+}
+
 // per-pixel sums, block by block in ascending order (the arithmetic spec's summation order: samples are summed in
 // order inside aligned blocks of kSumBlock, the block sums in order)
 __global__ void __launch_bounds__(kBlock) k_resolve_blocks(const float4* __restrict__ blocksum, float4* __restrict__ accum, uint32_t npix, uint32_t nblocks) {

@@ -208,8 +208,9 @@ def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
             {"RTW_TAIL_START": "2"}, {"RTW_TAIL_START": "40", "RTW_GRID_MULT": "1"}, {"RTW_LDS_KB": "0"},
             {"RTW_LDS_KB": "48", "RTW_BRUTE_MAX": "0"}, {"RTW_POOL_PATHS": "4096", "RTW_GRID_MULT": "3"},
             {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "0"}, {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "30"}]
-    knobs = [{}, {"RTW_PATH": "2"}, {"RTW_PATH": "2", "RTW_BRUTE_MAX": "0", "RTW_PATH_JOB_BLOCKS": "1", "RTW_PATH_GRID_MULT": "1"},
-             {"RTW_PATH_JOB_BLOCKS": "7", "RTW_BLOCKSUM_BYTES": "65536"}, {"RTW_PATH_GRID_MULT": "2", "RTW_KERNEL_TIMING": "0"}]
+    knobs = [{}, {"RTW_PATH_TREE": "1"}, {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_PATH_JOB_BLOCKS": "1", "RTW_PATH_GRID_MULT": "1"},
+             {"RTW_PATH_JOB_BLOCKS": "7", "RTW_BLOCKSUM_BYTES": "65536"}, {"RTW_PATH_GRID_MULT": "2", "RTW_KERNEL_TIMING": "0"},
+             {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_LDS_KB": "0"}, {"RTW_PATH_TREE": "1", "RTW_LDS_KB": "40"}]
     knobs += [dict(k, RTW_PATH="0") for k in wave]
     names = sorted({k for kn in knobs for k in kn})
     for blob, w, h, spp, depth in cases:
@@ -322,7 +323,7 @@ def test_error_behaviour():
     lib = abi.load_hip()
     ctx = C.c_void_p()
     dev = (C.c_int * 1)(0)
-    assert lib.rtw_create(C.byref(ctx), 2, dev) == -6  # one context per GPU
+    assert lib.rtw_create(C.byref(ctx), 0, dev) == -1 and lib.rtw_create(C.byref(ctx), 65, dev) == -1  # 1..64 devices
     assert lib.rtw_create(C.byref(ctx), 1, dev) == 0
     out = np.zeros((4, 4, 4), np.float32)
     st = abi.Stats()
