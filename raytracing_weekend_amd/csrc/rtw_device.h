@@ -619,14 +619,16 @@ RTW_DEV uint32_t bvh_inner_step(const DScene& sc, const TravMem& tm, const v3 o,
 
 // Conservative: false only when the ray certainly stays outside the scene bounds (NaNs from 0 * inf answer "may hit").
 RTW_DEV bool may_hit_scene(const DScene& sc, const v3 o, const v3 d) {
-    const v3 inv = V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    // hardware reciprocals (1 ulp): the bounds are padded by 1 % of the scene diagonal, and the answer only decides
+    // whether a wave walks its candidate lists, never what a walk returns
+    const v3 inv = V(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     const float ax = (sc.bmin[0] - o.x) * inv.x, bx = (sc.bmax[0] - o.x) * inv.x;
     const float ay = (sc.bmin[1] - o.y) * inv.y, by = (sc.bmax[1] - o.y) * inv.y;
     const float az = (sc.bmin[2] - o.z) * inv.z, bz = (sc.bmax[2] - o.z) * inv.z;
     const float tnear = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), 0.0f));
     const float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fmaxf(az, bz));
     const bool any_nan = !(ax == ax && bx == bx && ay == ay && by == by && az == az && bz == bz);
-    return any_nan || !(tnear > tfar);
+    return any_nan || !(tnear > tfar * 1.001f);
 }
 
 RTW_DEV bool uses_inv(int type) { return type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_VOLUME_BOX; }
@@ -730,27 +732,63 @@ RTW_DEV void traverse_brute(const DScene& sc, v3 o, v3 d, float tmin, float tmax
 
 // ---- k_path's walk: the candidate lists in LDS ----------------------------------------------------------------------
 // The same groups, records and order as traverse_brute, copied by the workgroup into LDS at kernel start and read by
-// every lane of a wave at the same address (broadcast reads): an LDS round trip per candidate instead of a scalar-cache
-// one, which is what bounded k_path's walks (two thirds of their wave-cycles were s_waitcnt on s_load).
-// Image, in 16-byte words: groups (2 words each: BruteGroup), then per group the 3 rows of its world->object matrix,
-// then the records (2 words each: BruteRec). Arithmetic per ray: exactly traverse_brute's.
+// every lane of a wave at the same address (broadcast reads, returned in order): while one record is under test the
+// next one is already on its way (two register sets, A and B, take turns), so a walk waits for LDS once, not once per
+// candidate. Image, in 16-byte words: groups (2 words each: BruteGroup), then per group the 3 rows of its world->object
+// matrix, then the records (2 words each: BruteRec with prim + 1 in place of prim), then two words of padding.
+// The arithmetic per ray is traverse_brute's; the tests are stated so that they need fewer instructions:
+//   lo <= a <= hi        as  med3(a, lo, hi) == a   (finite lo <= hi; a NaN fails both forms)
+//   closest hit, ties to the lowest primitive index: (t, prim + 1) < (best_t, best_prim + 1) as ONE unsigned 64-bit
+//                        compare of (bits(t) << 32 | prim + 1): t > 0 where it matters, so bits(t) orders like t
+//   any hit              no running minimum at all: occluded |= hit & (t < tmax)
 constexpr int kWalkMaxWords = 400;  // 6.4 KB of LDS; scenes whose lists are larger use the wavefront kernels
+struct WalkRec { u32x4 q0, q1; };
+RTW_DEV bool in_range(float a, uint32_t lo, uint32_t hi) { return __builtin_amdgcn_fmed3f(a, __uint_as_float(lo), __uint_as_float(hi)) == a; }
+
 template <bool ANY_HIT>
 RTW_DEV void walk_lds(const u32x4* __restrict__ w, const int n_groups, const v3 o, const v3 d, const float tmin, const float tmax, float& best_t, int& best_prim) {
-    best_t = tmax;
-    best_prim = -1;
-#define RTW_TAKE(HIT_, T_, PI_)                                                                      \
-    {                                                                                                \
-        const bool tie_ = !ANY_HIT && ((T_) == best_t) & ((PI_) < best_prim);                        \
-        const bool take_ = (HIT_) & (((T_) < best_t) | tie_);                                        \
-        best_t = take_ ? (T_) : best_t;                                                              \
-        best_prim = take_ ? (PI_) : best_prim;                                                       \
-    }
+    // closest hit: key = bits(best_t) << 32 | best_prim + 1; any hit: key_lo = 1 once occluded
+    uint32_t key_hi = __float_as_uint(tmax), key_lo = 0u;
     const u32x4* xf = w + 2 * n_groups;
-    const u32x4* rec = w + 5 * n_groups;
+    const u32x4* r = w + 5 * n_groups;  // the record stream: groups follow each other without gaps
+    WalkRec A, B;
+    A.q0 = r[0]; A.q1 = r[1];
+#define RTW_RECT_TEST(R_, OK_, IK_, OA_, DA_, OB_, DB_)                                              \
+    {                                                                                                \
+        const float t = (__uint_as_float(R_.q1.x) - (OK_)) * (IK_);                                  \
+        const float a = fma_(t, (DA_), (OA_));                                                       \
+        const float b = fma_(t, (DB_), (OB_));                                                       \
+        const bool hit = (t >= tmin) & in_range(a, R_.q0.x, R_.q0.y) & in_range(b, R_.q0.z, R_.q0.w); \
+        if (ANY_HIT) {                                                                               \
+            key_lo = (hit & (t < tmax)) ? 1u : key_lo;                                               \
+        } else {                                                                                     \
+            const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | R_.q1.y; \
+            const bool take = hit & (key < (((unsigned long long)key_hi << 32) | key_lo));           \
+            key_hi = take ? __float_as_uint(t) : key_hi;                                             \
+            key_lo = take ? R_.q1.y : key_lo;                                                        \
+        }                                                                                            \
+    }
+// n records of one kind: A holds the first on entry and the first record after the list on exit
+#define RTW_REC_LIST(N_, TEST_)                                                                      \
+    {                                                                                                \
+        int n_ = (N_);                                                                               \
+        for (; n_ >= 2; n_ -= 2) {                                                                   \
+            B.q0 = r[2]; B.q1 = r[3];                                                                \
+            TEST_(A)                                                                                 \
+            A.q0 = r[4]; A.q1 = r[5];                                                                \
+            TEST_(B)                                                                                 \
+            r += 4;                                                                                  \
+        }                                                                                            \
+        if (n_ > 0) {                                                                                \
+            B.q0 = r[2]; B.q1 = r[3];                                                                \
+            TEST_(A)                                                                                 \
+            A = B;                                                                                   \
+            r += 2;                                                                                  \
+        }                                                                                            \
+    }
     for (int gi = 0; gi < n_groups; gi++) {
         const u32x4 g0 = w[2 * gi], g1 = w[2 * gi + 1];
-        const int g_xform = (int)__builtin_amdgcn_readfirstlane(g0.x), first = (int)__builtin_amdgcn_readfirstlane(g0.y);
+        const int g_xform = (int)__builtin_amdgcn_readfirstlane(g0.x);
         const int n_rx = (int)__builtin_amdgcn_readfirstlane(g0.z), n_ry = (int)__builtin_amdgcn_readfirstlane(g0.w);
         const int n_rz = (int)__builtin_amdgcn_readfirstlane(g1.x), n_sph = (int)__builtin_amdgcn_readfirstlane(g1.y);
         v3 oo = o, dd = d;
@@ -763,32 +801,39 @@ RTW_DEV void walk_lds(const u32x4* __restrict__ w, const int n_groups, const v3 
             oo = xf_point(m, o);
             dd = xf_vector(m, d);
         }
-        const u32x4* r = rec + 2 * first;
         if (n_rx + n_ry + n_rz > 0) {
             const v3 inv = recip3(dd);
-#define RTW_RECT_LOOP(N_, OK_, IK_, OA_, DA_, OB_, DB_)                                              \
-            for (int i = 0; i < (N_); i++, r += 2) {                                                 \
-                const u32x4 q0 = r[0], q1 = r[1];                                                    \
-                const float t = (__uint_as_float(q1.x) - (OK_)) * (IK_);                             \
-                const float a = fma_(t, (DA_), (OA_));                                               \
-                const float b = fma_(t, (DB_), (OB_));                                               \
-                const bool hit = (t >= tmin) & (a >= __uint_as_float(q0.x)) & (a <= __uint_as_float(q0.y)) & \
-                                 (b >= __uint_as_float(q0.z)) & (b <= __uint_as_float(q0.w));        \
-                RTW_TAKE(hit, t, (int)q1.y)                                                          \
-            }
-            RTW_RECT_LOOP(n_rx, oo.x, inv.x, oo.y, dd.y, oo.z, dd.z)   // shaders/aarectx.cu:8-22
-            RTW_RECT_LOOP(n_ry, oo.y, inv.y, oo.x, dd.x, oo.z, dd.z)   // shaders/aarecty.cu:8-22
-            RTW_RECT_LOOP(n_rz, oo.z, inv.z, oo.x, dd.x, oo.y, dd.y)   // shaders/aarectz.cu:9-23
-#undef RTW_RECT_LOOP
+#define RTW_TEST_X(R_) RTW_RECT_TEST(R_, oo.x, inv.x, oo.y, dd.y, oo.z, dd.z)   /* shaders/aarectx.cu:8-22 */
+#define RTW_TEST_Y(R_) RTW_RECT_TEST(R_, oo.y, inv.y, oo.x, dd.x, oo.z, dd.z)   /* shaders/aarecty.cu:8-22 */
+#define RTW_TEST_Z(R_) RTW_RECT_TEST(R_, oo.z, inv.z, oo.x, dd.x, oo.y, dd.y)   /* shaders/aarectz.cu:9-23 */
+            RTW_REC_LIST(n_rx, RTW_TEST_X)
+            RTW_REC_LIST(n_ry, RTW_TEST_Y)
+            RTW_REC_LIST(n_rz, RTW_TEST_Z)
+#undef RTW_TEST_X
+#undef RTW_TEST_Y
+#undef RTW_TEST_Z
         }
-        for (int i = 0; i < n_sph; i++, r += 2) {
-            const u32x4 q0 = r[0], q1 = r[1];
-            float t = 0.f;
-            const bool hit = sphere_roots(oo, dd, V(__uint_as_float(q0.x), __uint_as_float(q0.y), __uint_as_float(q0.z)), __uint_as_float(q0.w), tmin, RTW_FLT_MAX, t);
-            RTW_TAKE(hit, t, (int)q1.y)
+#define RTW_TEST_SPH(R_)                                                                             \
+        {                                                                                            \
+            float t = 0.f;                                                                           \
+            const bool hit = sphere_roots(oo, dd, V(__uint_as_float(R_.q0.x), __uint_as_float(R_.q0.y), __uint_as_float(R_.q0.z)), \
+                                          __uint_as_float(R_.q0.w), tmin, RTW_FLT_MAX, t);           \
+            if (ANY_HIT) {                                                                           \
+                key_lo = (hit & (t < tmax)) ? 1u : key_lo;                                           \
+            } else {                                                                                 \
+                const unsigned long long key = ((unsigned long long)__float_as_uint(t) << 32) | R_.q1.y; \
+                const bool take = hit & (key < (((unsigned long long)key_hi << 32) | key_lo));       \
+                key_hi = take ? __float_as_uint(t) : key_hi;                                         \
+                key_lo = take ? R_.q1.y : key_lo;                                                    \
+            }                                                                                        \
         }
+        RTW_REC_LIST(n_sph, RTW_TEST_SPH)
+#undef RTW_TEST_SPH
     }
-#undef RTW_TAKE
+#undef RTW_REC_LIST
+#undef RTW_RECT_TEST
+    best_t = ANY_HIT ? tmax : __uint_as_float(key_hi);
+    best_prim = (int)key_lo - 1;
 }
 
 // Closest / any hit (optixTraverse at raygen.cu:41-54 and closehit.cu:27-40).

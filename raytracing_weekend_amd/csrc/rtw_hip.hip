@@ -540,10 +540,12 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!use_bvh && n_generic == 0 && !groups.empty()) {
         static_assert(sizeof(BruteGroup) == 32 && sizeof(BruteRec) == 32, "walk image layout");
         const size_t ng = groups.size();
-        walk.resize((5 * ng + 2 * recs.size()) * 4, 0u);
+        walk.resize((5 * ng + 2 * recs.size() + 4) * 4, 0u);  // + 4 words: the reader fetches up to two records ahead
         memcpy(walk.data(), groups.data(), ng * sizeof(BruteGroup));
         for (size_t g = 0; g < ng; g++) memcpy(walk.data() + (2 * ng + 3 * g) * 4, xforms[groups[g].xform].inv, 12 * sizeof(float));
         if (!recs.empty()) memcpy(walk.data() + 5 * ng * 4, recs.data(), recs.size() * sizeof(BruteRec));
+        for (size_t i = 0; i < recs.size(); i++) walk[(5 * ng + 2 * i) * 4 + 5] = (uint32_t)recs[i].prim + 1u;  // the walk's tie key
+        // (a rectangle with lo > hi can never be hit under either form of the range test, so none needs removing)
         if (walk.size() / 4 > (size_t)kWalkMaxWords) walk.clear();
     }
     rtwbvh::Bvh bvh;
