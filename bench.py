@@ -19,7 +19,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 WIDTH, HEIGHT, SPP, DEPTH, SEED = 1920, 1080, 4096, 50, 0x6314759
+CONFIGS = {"headline": (1920, 1080, 4096), "c5": (7680, 4320, 4096)}  # BASELINE.json: the metric workload, and config 5
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 2.0  # wave64 VALU instructions per ns, chip-wide: 256 CUs x 4 SIMD-32 x 2.4 GHz / 2 cycles (same guide)
 
 
 def cpu_baseline(blob, abi):
@@ -57,7 +59,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="override samples per pixel (a reduced-spp line is not the headline metric)")
+    ap.add_argument("--config", default="headline", choices=sorted(CONFIGS), help="headline: Cornell box 1920x1080 4096 spp (the metric); "
+                    "c5: BASELINE config 5, Cornell box 7680x4320 4096 spp (row shards over the GPUs)")
+    ap.add_argument("--spp", type=int, default=None, help="override samples per pixel (a reduced-spp line is not the headline metric)")
     ap.add_argument("--rng", type=int, default=0, help="0 Philox4x32-10 (default), 1 the reference's TEA+LCG")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N>1: nccl (= RCCL over xGMI) or gloo "
@@ -65,6 +69,10 @@ def main():
     ap.add_argument("--check", action="store_true", help="rank 0 re-renders the full frame alone and asserts the gathered image is identical")
     args = ap.parse_args()
 
+    global WIDTH, HEIGHT
+    WIDTH, HEIGHT, spp_cfg = CONFIGS[args.config]
+    if args.spp is None:
+        args.spp = spp_cfg
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this pool
     import torch
     import torch.distributed as dist
@@ -73,8 +81,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start N > 1 ranks with `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...` (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     dev_index = local_rank % torch.cuda.device_count()
@@ -150,10 +159,10 @@ def main():
         if not torch.equal(full, alone.cpu()):
             raise SystemExit("gathered row tiles differ from the single-tile render")
     if rank == 0:
-        # Dominant kernel of rank 0 = the wavefront kernel with the largest summed device time. Its
-        # algorithmic bytes are 128 B per radiance segment it processed (64 B of SoA path state read
-        # and written once per segment; for k_trace, per ray pair traced); its time is measured live with HIP
-        # events recorded on the launch stream around every launch inside rtw_render_device.
+        # Dominant kernel of rank 0 = the path-tracing kernel with the largest summed device time (k_path on the metric
+        # workload). Its algorithmic bytes are 128 B per radiance segment it processed (64 B of path state read
+        # and written once per segment; for k_trace, per ray pair traced); its time is measured live with HIP events
+        # recorded on the launch stream around every launch inside rtw_render_device.
         names = abi.Stats.KERNELS
         NK = len(names)
         k_s = [sum(s.kernel_seconds[i] for s in stats) for i in range(NK)]
@@ -162,19 +171,31 @@ def main():
         dom = max(range(NK), key=lambda i: k_s[i])
         seg0 = float(sum(s.segments for s in stats))
         b_s, b_n, r_s = (float(x) for x in kt.tolist())
-        dom_units = float(k_seg[dom]) if dom != 2 else float(k_seg[dom]) / 2.0
+        dom_units = float(k_seg[dom]) if names[dom] != "k_trace" else float(k_seg[dom]) / 2.0
         achieved = 128.0 * dom_units / k_s[dom] / 1e9 if k_s[dom] > 0 else 0.0
         loop_achieved = 128.0 * seg0 / b_s / 1e9 if b_s > 0 else 0.0
-        traffic = None
+        # Measured HBM traffic and instruction counts PER SEGMENT of that kernel come from the committed rocprofv3 --pmc
+        # summary (profiles/pmc_traffic.json: FETCH_SIZE x 2 + WRITE_SIZE and SQ_INSTS_VALU of a profiled run of the same
+        # kernel on the same scene); they are scaled here by the units this run's launches processed.
+        traffic, pmc_rec, valu = None, None, None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
-                    traffic = json.load(f).get(names[dom] + "_hbm_bytes_per_launch")
+                    pmc_rec = json.load(f).get(names[dom])
+                if pmc_rec and k_n[dom]:
+                    traffic = int(pmc_rec["hbm_bytes_per_segment"] * dom_units / k_n[dom])
+                    if pmc_rec.get("valu_insts_per_segment") and k_s[dom] > 0:
+                        rate = pmc_rec["valu_insts_per_segment"] * dom_units / k_s[dom] / 1e9
+                        valu = {"wave_insts_per_64_segments": round(64.0 * pmc_rec["valu_insts_per_segment"], 1),
+                                "achieved_Ginst_per_s": round(rate, 1), "peak_Ginst_per_s": VALU_PEAK_GINST,
+                                "frac": round(rate / VALU_PEAK_GINST, 4), "lane_utilisation": pmc_rec.get("lane_utilisation")}
             except Exception:
                 traffic = None
+        in_regs = names[dom] == "k_path"
+        cfg_name = "Cornell box 1920x1080 4096spp" if args.config == "headline" else "Cornell box 7680x4320 4096spp (BASELINE config 5)"
         line = {
-            "metric": "Msamples/s, Cornell box 1920x1080 4096spp",
+            "metric": f"Msamples/s, {cfg_name}",
             "value": round(samples / dt_max / 1e6, 3),
             "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -190,18 +211,24 @@ def main():
                        "partition": f"{world} interleaved row shards (rank g: rows g, g+{world}, ...; {max_rows} rows each), one RCCL gather per step" if world > 1 else "single tile",
                        "segments_per_sample": round(segments / samples, 4),
                        "shadow_rays_per_sample": round(shadow / samples, 4),
-                       "paths_in_flight": int(os.environ.get("RTW_POOL_PATHS", 1 << 28)),
-                       "lanes": int(os.environ.get("RTW_LANES", 2))},
+                       "pipeline": "k_path: paths in registers, lanes own (pixel, 64-sample block) units and regenerate" if in_regs
+                                   else "wavefront: k_first / k_trace / k_shade / k_bounce over SoA path state in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                         "traffic_source": "profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE per segment of a "
+                                           "profiled run, x this run's segments per launch)" if traffic is not None else None,
                          "kernel": names[dom], "launches": int(k_n[dom]),
                          "avg_launch_us": round(k_s[dom] / k_n[dom] * 1e6, 3) if k_n[dom] else None,
                          "algorithmic_bytes_per_launch": round(128.0 * dom_units / k_n[dom], 1) if k_n[dom] else None,
-                         "note": "two batches are in flight on two streams (lanes), so a kernel's own launch duration "
-                                 "includes sharing the GPU with the other lane's kernels; whole_loop is the unshared figure",
+                         "note": ("achieved = 128 B x segments / kernel time (SURVEY 8d). k_path never writes path state: the state the "
+                                  "algorithmic figure counts stays in registers, only 16 B per pixel and 64 samples reach HBM (traffic), so "
+                                  "the kernel is bound by VALU issue, not by HBM: see roofline.valu") if in_regs else
+                                 "two batches are in flight on two streams (lanes), so a kernel's own launch duration includes sharing "
+                                 "the GPU with the other lane's kernels; whole_loop is the unshared figure",
+                         "valu": valu,
                          "whole_loop": {"achieved": round(loop_achieved, 2), "frac": round(loop_achieved / HBM_PEAK_GBS, 5),
                                         "seconds": round(b_s, 4), "launches": int(b_n),
-                                        "note": "128 B x all segments / device time of the render calls (all four kernels, both lanes)"},
+                                        "note": "128 B x all segments / device time of the render calls (every kernel, resolve included)"},
                          "per_kernel": {names[i]: {"seconds": round(k_s[i], 4), "launches": int(k_n[i]), "units": int(k_seg[i])}
                                         for i in range(NK) if k_n[i]},
                          "render_device_seconds_rank0": round(r_s, 4)},

@@ -17,6 +17,18 @@ for d in sorted(glob.glob(os.path.join(out, "p*"))):
     big = max(per, key=lambda k: sum(per[k].values()))
     for c, v in per[big].items():
         tot[c] = v
+# the profiled command's own JSON line (scripts/bench_scene.py): units = radiance segments the kernel processed in the main render
+units = None
+for lg in sorted(glob.glob(os.path.join(out, "p*.log"))):
+    for line in open(lg, errors="ignore"):
+        if line.startswith("{") and '"kernels"' in line:
+            try:
+                kk = json.loads(line)["kernels"]
+                for name, v in kk.items():
+                    if name in kern or kern in name:
+                        units = v["units"]
+            except Exception:
+                pass
 def r(a, b):
     return tot.get(a, 0.0) / tot[b] if tot.get(b) else None
 der = {
@@ -28,6 +40,11 @@ der = {
     "ifetch_latency": r("SQ_IFETCH_LEVEL", "SQ_IFETCH"), "waves_per_sq_cycle": r("SQ_LEVEL_WAVES", "SQ_CYCLES"),
     "hbm_bytes": (2.0 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0 if ("FETCH_SIZE" in tot or "WRITE_SIZE" in tot) else None,
 }
+if units:
+    der["segments"] = units
+    der["hbm_bytes_per_segment"] = der["hbm_bytes"] / units if der.get("hbm_bytes") is not None else None
+    der["valu_insts_per_segment"] = tot.get("SQ_INSTS_VALU", 0.0) / units
+    der["salu_insts_per_segment"] = tot.get("SQ_INSTS_SALU", 0.0) / units
 json.dump({"kernel": kern, "counters": tot, "derived": der}, open(os.path.join(out, "summary.json"), "w"), indent=1)
 print(json.dumps(der, indent=1))
 print(" ".join(f"{k.replace('SQ_', '')}={v:.4g}" for k, v in sorted(tot.items())))
