@@ -29,6 +29,11 @@
 
 #include "../include/rtw.h"
 
+/* Test hook (tests/test_oracle_physics.py): rtwo_set_debug(1) switches Russian roulette off, to check that the roulette of
+ * raygen.cu:74-82 leaves the expectation alone. Never set by the parity tests. */
+static int g_debug_no_roulette = 0;
+void rtwo_set_debug(int no_roulette) { g_debug_no_roulette = no_roulette; }
+
 /* ------------------------------------------------------------------ vec3 */
 typedef struct { float x, y, z; } v3;
 
@@ -251,6 +256,9 @@ static int scene_open(scene_t* s, const void* blob, size_t bytes) {
     if ((size_t)h->off_textures + (size_t)h->n_textures * sizeof(rtw_texture) > bytes) return RTW_ERR_BAD_SCENE;
     if ((size_t)h->off_lights + (size_t)h->n_lights * sizeof(rtw_light) > bytes) return RTW_ERR_BAD_SCENE;
     if (h->n_xforms < 1) return RTW_ERR_BAD_SCENE;
+    /* include/rtw.h: tables sit at 16-byte aligned offsets (the tables are read in place here) */
+    if ((h->off_prims | h->off_xforms | h->off_materials | h->off_textures | h->off_lights | h->off_texdata) & 15u) return RTW_ERR_BAD_SCENE;
+    if (((uintptr_t)blob & 3u) != 0) return RTW_ERR_BAD_SCENE;
     s->h = h;
     s->clights = NULL;
     s->listed = NULL;
@@ -1025,8 +1033,11 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
         if (2 <= depth) {
             /* raygen.cu:74-82 */
             float p = fmaxf(fmaxf(T.x, T.y), T.z);
-            if (p < rng_rr(&g)) break;
-            T = vscale(T, 1.0f / p);
+            float xi = rng_rr(&g);
+            if (!g_debug_no_roulette) {  /* (the draw is consumed either way, so both settings walk the same streams) */
+                if (p < xi) break;
+                T = vscale(T, 1.0f / p);
+            }
         }
         depth++;
     }

@@ -365,6 +365,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         !in_range(h.off_materials, h.n_materials, sizeof(rtw_material)) || !in_range(h.off_textures, h.n_textures, sizeof(rtw_texture)) ||
         !in_range(h.off_lights, h.n_lights, sizeof(rtw_light)) || h.n_xforms < 1)
         return fail(c, RTW_ERR_BAD_SCENE, "scene table out of range");
+    if ((h.off_prims | h.off_xforms | h.off_materials | h.off_textures | h.off_lights | h.off_texdata) & 15u)
+        return fail(c, RTW_ERR_BAD_SCENE, "scene table not 16-byte aligned");
     const char* b = (const char*)blob;
     std::vector<rtw_prim> prims(h.n_prims);
     std::vector<rtw_xform> xforms(h.n_xforms);

@@ -25,8 +25,8 @@ void Director::init(unsigned int width, unsigned int height, unsigned int sample
     m_Nx = static_cast<int>(width);
     m_Ny = static_cast<int>(height);
     m_Ns = static_cast<int>(samples);
-    int dev = m_device;
-    int rc = rtw_create(&m_ctx, 1, &dev);
+    if (m_devices.empty()) m_devices.assign(1, 0);
+    int rc = rtw_create(&m_ctx, static_cast<int>(m_devices.size()), m_devices.data());
     if (rc != RTW_OK) die(nullptr, "rtw_create", rc);
     m_hostBuffer.assign(static_cast<size_t>(m_Nx) * m_Ny * 4, 0.f);
 }

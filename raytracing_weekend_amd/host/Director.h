@@ -29,7 +29,10 @@ public:
     void setMaxDepth(int depth) { m_maxRayDepth = depth; }
     void setSeed(uint32_t seed) { m_seed = seed; }
     void setRngKind(int kind) { m_rngKind = kind; }
-    void setDevice(int device) { m_device = device; }
+    void setDevice(int device) { m_devices.assign(1, device); }
+    // n GPUs of this node, devices first .. first + n - 1: the frame is split into n interleaved row shards inside the library
+    // (rtw_create with n_devices = n) and gathered on the first device; the image does not depend on n
+    void setDevices(int n, int first = 0, bool same = false) { m_devices.clear(); for (int i = 0; i < n; i++) m_devices.push_back(same ? first : first + i); }
     void setEstimator(int estimator) { m_estimator = estimator; }  // rtw_estimator
     // the reference's renderFrame ends with the OptiX AI denoiser (Director.cpp:986-997); iterations > 0 runs the
     // a-trous stand-in (rtw_denoise) on the frame instead
@@ -44,7 +47,7 @@ private:
     int m_maxRayDepth = 20;
     uint32_t m_seed = 0x6314759u;
     int m_rngKind = RTW_RNG_PHILOX;
-    int m_device = 0;
+    std::vector<int> m_devices{0};
     int m_estimator = RTW_EST_REFERENCE;
     int m_denoiseIterations = 0;
     float m_denoiseSigma = 0.5f;

@@ -1,10 +1,11 @@
 // main.cpp — command-line front end, same flow and flags as the reference (RestOfLife/main.cpp:29-165):
 //   -s scene  -ns samples  -dx width  -dy height  -h  -v  -g
 // plus what the benchmark configurations need and the reference hard-wires:
-//   -d depth (reference: 20, Director.cpp:42)   -seed N   -rng philox|lcg   -gpu id   -o file.ppm|file.png|file.pfm
+//   -d depth (reference: 20, Director.cpp:42)   -seed N   -rng philox|lcg   -gpu id   -gpus N   -o file.ppm|file.png|file.pfm
 // The reference's resolution / sample clamps (main.cpp:21-27) are widened so that 200x200 and
 // 7680x4320 are reachable, and its scene range bug (only scene 4 selectable, main.cpp:69) is not kept.
 #include <chrono>
+#include <cstdlib>
 #include <iostream>
 #include <stdexcept>
 #include <string>
@@ -41,7 +42,7 @@ int clampWarn(const char* what, int x, int lo, int hi) {
 }  // namespace
 
 int main(int argc, char* argv[]) {
-    int Nx = 1200, Ny = 600, Nscene = 0, Ns = 20, depth = 20, gpu = 0;
+    int Nx = 1200, Ny = 600, Nscene = 4, Ns = 20, depth = 20, gpu = 0, gpus = 1;  // the reference's defaults (main.cpp:32-37)
     uint32_t seed = 0x6314759u;
     int rng = RTW_RNG_PHILOX;
 
@@ -60,7 +61,8 @@ int main(int argc, char* argv[]) {
     -denoise N     N passes (1..8) of the a-trous filter that stands in for the reference's AI denoiser (default: off)
     -est K         reference (default: the reference's estimator, quirks included), corrected, or brute
                    (corrected without light sampling)
-    -gpu N         Device ordinal
+    -gpu N         Device ordinal (the first one with -gpus)
+    -gpus N        Render on N GPUs of this node: interleaved row shards, one gather onto the first device (default 1)
     -o FILE        Write FILE instead of ASCII P3 on stdout: *.ppm = binary P6, *.png = 8-bit PNG, *.pfm = linear float PFM
 
     -h             This help message.
@@ -86,6 +88,7 @@ int main(int argc, char* argv[]) {
     if (intOption(cl_input, "-dy", "image height (-dy)", x)) Ny = clampWarn("Height (-dy)", x, Ny_MIN, Ny_MAX);
     if (intOption(cl_input, "-d", "depth (-d)", x)) depth = clampWarn("Depth (-d)", x, 1, 1 << 20);
     if (intOption(cl_input, "-gpu", "device (-gpu)", x)) gpu = x;
+    if (intOption(cl_input, "-gpus", "number of devices (-gpus)", x)) gpus = clampWarn("Number of devices (-gpus)", x, 1, 64);
     if (intOption(cl_input, "-seed", "seed", x)) seed = static_cast<uint32_t>(x);
     const std::string& rngName = cl_input.getCmdOption("-rng");
     if (rngName == "lcg") rng = RTW_RNG_TEA_LCG;
@@ -98,7 +101,9 @@ int main(int argc, char* argv[]) {
     else if (!estName.empty() && estName != "reference") std::cerr << "WARNING: unknown -est " << estName << ", using reference" << std::endl;
 
     Director director(Qverbose, Qdebug);
-    director.setDevice(gpu);
+    // RTW_SAME_DEVICE=1 (tests on a one-GPU box): all -gpus N shards render on device -gpu
+    if (gpus > 1) director.setDevices(gpus, gpu, std::getenv("RTW_SAME_DEVICE") != nullptr);
+    else director.setDevice(gpu);
     director.setMaxDepth(depth);
     director.setSeed(seed);
     director.setRngKind(rng);

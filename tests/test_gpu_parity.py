@@ -499,6 +499,10 @@ def test_cli_director_outputs(tmp_path):
     blob = abi.build_scene(0, w, h)
     ref, _ = oracle.render(blob, abi.make_params(w, h, spp, depth), threads=8)
     assert np.array_equal(img, ref[..., :3])
+    # -gpus 3: three interleaved shards inside the library (all on this box's one GPU), gathered: the same file
+    pfm3 = str(tmp_path / "o3.pfm")
+    subprocess.run(args + ["-gpus", "3", "-o", pfm3], check=True, timeout=300, env=dict(os.environ, RTW_SAME_DEVICE="1"))
+    assert open(pfm3, "rb").read() == raw
     png = str(tmp_path / "o.png")
     subprocess.run(args + ["-o", png], check=True, timeout=300)
     rawp = open(ppm, "rb").read()

@@ -1,0 +1,228 @@
+"""Pins for the CPU oracle that do not come from the oracle itself (the reference holds no fixtures, so
+analytic answers are the only independent check of the restatement): furnace scenes whose radiance is known exactly,
+the closed-form direct light of a rectangle on a parallel plane, and Russian roulette leaving the expectation alone.
+Also the sanitized oracle build, in a subprocess. CPU only."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from raytracing_weekend_amd import abi
+
+
+def tex(rgb):
+    t = abi.Texture(type=abi.TEX_CONSTANT)
+    t.color[0], t.color[1], t.color[2] = (float(v) for v in rgb)
+    return t
+
+
+def prim(ptype, params, material, flip=0):
+    pr = abi.Prim(type=ptype, material=material, xform=0, flip=flip)
+    for k, v in enumerate(params):
+        pr.p[k] = float(v)
+    return pr
+
+
+def scene(w, h, prims, materials, textures, lights=(), sky=0, pdf_rect=None):
+    """Blob with the Cornell camera (at (278, 278, -800) looking down +z) and the given tables."""
+    parts = dict(abi.parse_scene(abi.build_scene(0, w, h)))
+    hdr = abi.SceneHeader.from_buffer_copy(bytes(parts["header"]))
+    hdr.sky_light = sky
+    if pdf_rect is not None:
+        for k, v in enumerate(pdf_rect):
+            hdr.pdf.rect[k] = float(v)
+    ident = list(parts["xforms"])[:1]
+    parts.update(header=hdr, prims=list(prims), xforms=ident, materials=list(materials), textures=list(textures), lights=list(lights))
+    return abi.assemble_scene(parts)
+
+
+def emitter_room(le):
+    """Six inward-facing emitting rectangles around the Cornell cube, camera side included (the camera sits outside and
+    looks through the z = -1000 wall's back face, which does not emit towards it: diffuseLight.cu:52 tests n.d < 0)."""
+    lo, hi = -1000.0, 1600.0
+    return [prim(abi.PRIM_RECT_X, (lo, hi, lo, hi, lo), 0, flip=0), prim(abi.PRIM_RECT_X, (lo, hi, lo, hi, hi), 0, flip=1),
+            prim(abi.PRIM_RECT_Y, (lo, hi, lo, hi, lo), 0, flip=0), prim(abi.PRIM_RECT_Y, (lo, hi, lo, hi, hi), 0, flip=1),
+            prim(abi.PRIM_RECT_Z, (lo, hi, lo, hi, lo), 0, flip=0), prim(abi.PRIM_RECT_Z, (lo, hi, lo, hi, hi), 0, flip=1)]
+
+
+@pytest.mark.parametrize("est", [abi.RTW_EST_REFERENCE, abi.RTW_EST_CORRECTED])
+@pytest.mark.parametrize("rng", [abi.RTW_RNG_PHILOX, abi.RTW_RNG_TEA_LCG])
+def test_furnace_radiance_is_exact(est, rng):
+    """A convex object inside a closed room of uniform emitters (Le = 1, no listed lights): every path that reaches the
+    object scatters once and then meets an emitter, so a pixel on a Lambertian sphere of albedo (0.5, 0.25, 1) is exactly
+    that albedo, on a glass sphere and on a fuzz-free white mirror exactly 1, beside them exactly Le - whatever the
+    sampler draws. Checks emission facing, throughput bookkeeping, the NaN scrub and that no path loses or gains energy."""
+    w, h = 64, 64
+    mats = [abi.Material(type=abi.MAT_DIFFUSE_LIGHT, texture=0, fuzz_or_eta=0.0, bsdf_eval=-1),
+            abi.Material(type=abi.MAT_LAMBERTIAN, texture=1, fuzz_or_eta=0.0, bsdf_eval=0),
+            abi.Material(type=abi.MAT_DIELECTRIC, texture=-1, fuzz_or_eta=1.5, bsdf_eval=1),
+            abi.Material(type=abi.MAT_METAL, texture=2, fuzz_or_eta=0.0, bsdf_eval=2)]
+    texs = [tex((1, 1, 1)), tex((0.5, 0.25, 1.0)), tex((1, 1, 1))]
+    for mat, expect in ((1, (0.5, 0.25, 1.0)), (2, (1, 1, 1)), (3, (1, 1, 1))):
+        prims = emitter_room(1.0) + [prim(abi.PRIM_SPHERE, (278, 278, 278, 150), mat)]
+        blob = scene(w, h, prims, mats, texs)
+        img, st = oracle.render(blob, abi.make_params(w, h, 8, 50, rng_kind=rng, estimator=est), threads=4)
+        assert np.isfinite(img).all()
+        centre = img[h // 2 - 4:h // 2 + 4, w // 2 - 4:w // 2 + 4, :3]  # rays through the middle of the frame hit the sphere
+        corner = img[:4, :4, :3]
+        if mat == 2:
+            # glass: attenuation 1 and a roulette that divides by max(T) = 1, so a sample is exactly 1 - or exactly 0 when its
+            # path is still inside the sphere at the depth limit or produced a NaN that raygen.cu:17-24 zeroes (Q15)
+            assert set(np.unique(centre * 8)).issubset(set(np.arange(9, dtype=np.float32))) and centre.mean() > 0.95
+        elif est == abi.RTW_EST_REFERENCE and mat == 1:
+            # the reference starts scattered rays 1e-6 from the hit point, below the rounding of the point itself, so some
+            # re-hit the sphere they leave: each re-hit costs another factor of the albedo. The channel
+            # with albedo 1 stays exact; the others lie between albedo^2 and albedo.
+            assert np.array_equal(centre[..., 2], np.ones_like(centre[..., 2]))
+            for ch in (0, 1):
+                assert np.all(centre[..., ch] <= np.float32(expect[ch])) and np.all(centre[..., ch] >= np.float32(expect[ch]) ** 3)
+        elif est == abi.RTW_EST_REFERENCE and mat == 3:
+            # same quirk on the mirror: a reflected ray that re-hits the sphere from inside reflects inwards and is cancelled
+            # (metalMaterial.cu:56-60), so a sample is exactly 1 or exactly 0
+            assert set(np.unique(centre * 8)).issubset(set(np.arange(9, dtype=np.float32))) and 0.2 < centre.mean() < 0.9
+        else:
+            # exact sample by sample (albedo x Le) but for the rare grazing ray that re-enters the sphere it leaves: the hit
+            # point is rounded to +-2e-5 of the surface, and such a sample carries one more factor of the albedo
+            ex = np.broadcast_to(np.float32(expect), centre.shape)
+            assert np.all(centre <= ex) and np.all(centre >= ex * np.float32(0.9)) and np.mean(centre == ex) > 0.8
+            assert np.allclose(centre.mean(axis=(0, 1)), expect, rtol=0.01)
+        assert np.array_equal(corner, np.ones_like(corner))  # camera rays past the sphere see the far wall's emission
+
+
+def form_factor_parallel_rect(px, pz, x0, x1, z0, z1, hgt):
+    """Differential area at (px, 0, pz) facing +y to the rectangle [x0,x1] x [z0,z1] at height hgt, parallel to it
+    (sum of four corner configurations, e.g. Howell's catalogue B-4)."""
+    def corner(a, b):
+        sa, sb = np.sign(a) * np.sign(b), 1.0
+        a, b = abs(a) / hgt, abs(b) / hgt
+        if a == 0 or b == 0:
+            return 0.0
+        f = (a / np.sqrt(1 + a * a) * np.arctan(b / np.sqrt(1 + a * a)) + b / np.sqrt(1 + b * b) * np.arctan(a / np.sqrt(1 + b * b))) / (2 * np.pi)
+        return sa * sb * f
+    return corner(x1 - px, z1 - pz) - corner(x0 - px, z1 - pz) - corner(x1 - px, z0 - pz) + corner(x0 - px, z0 - pz)
+
+
+def test_direct_light_matches_the_form_factor():
+    """One segment (max depth 1) under RTW_EST_CORRECTED: the camera ray meets a Lambertian floor, the light sample is the
+    only contribution, so pixel = albedo * Le * F with F the closed-form point-to-rectangle form factor (no occluders).
+    Pins camera, rectangle intersection, light-sample geometry, pdf and the Lambertian f = albedo / pi against an
+    answer the oracle did not produce."""
+    w, h, spp = 48, 48, 4096
+    rho, le, hgt = np.array([0.73, 0.5, 0.2]), 15.0, 400.0
+    x0, x1, z0, z1 = 213.0, 343.0, 227.0, 332.0
+    mats = [abi.Material(type=abi.MAT_LAMBERTIAN, texture=0, fuzz_or_eta=0.0, bsdf_eval=0),
+            abi.Material(type=abi.MAT_DIFFUSE_LIGHT, texture=1, fuzz_or_eta=0.0, bsdf_eval=-1)]
+    texs = [tex(rho), tex((le, le, le))]
+    # a big floor (tilted view: the camera is moved up and looks down through the header below), the light above it
+    prims = [prim(abi.PRIM_RECT_Y, (-3000, 3000, -3000, 3000, 0.0), 0), prim(abi.PRIM_RECT_Y, (x0, x1, z0, z1, hgt), 1, flip=1)]
+    lt = abi.Light()
+    lt.position[0], lt.position[1], lt.position[2] = x0, hgt, z0
+    lt.vec_u[0], lt.vec_v[2] = x1 - x0, z1 - z0
+    lt.normal[1] = -1.0
+    lt.area = (x1 - x0) * (z1 - z0)
+    lt.emission[0] = lt.emission[1] = lt.emission[2] = le
+    blob = scene(w, h, prims, mats, texs, lights=[lt], pdf_rect=(x0, x1, z0, z1, hgt))
+    # camera: above the floor at (278, 250, -300), looking at (278, 0, 278) - built like scene/ioCamera.h:61-116
+    parts = dict(abi.parse_scene(blob))
+    hdr = abi.SceneHeader.from_buffer_copy(bytes(parts["header"]))
+    eye, at, up = np.array([278.0, 250.0, -300.0]), np.array([278.0, 0.0, 278.0]), np.array([0.0, 1.0, 0.0])
+    wv = (eye - at) / np.linalg.norm(eye - at)
+    uv = np.cross(up, wv); uv /= np.linalg.norm(uv)
+    vv = np.cross(wv, uv)
+    half_h = np.tan(np.deg2rad(40.0) / 2); half_w = half_h * w / h
+    cam = hdr.camera
+    for k in range(3):
+        cam.origin[k] = eye[k]; cam.u[k] = uv[k]; cam.v[k] = vv[k]; cam.w[k] = wv[k]
+        cam.lower_left[k] = eye[k] - half_w * uv[k] - half_h * vv[k] - wv[k]
+        cam.horizontal[k] = 2 * half_w * uv[k]; cam.vertical[k] = 2 * half_h * vv[k]
+    cam.lens_radius = 0.0
+    parts["header"] = hdr
+    blob = abi.assemble_scene(parts)
+    img, st = oracle.render(blob, abi.make_params(w, h, spp, 1, estimator=abi.RTW_EST_CORRECTED), threads=8)
+    assert st.segments == st.samples
+    checked = 0
+    for (px_, py_) in ((24, 24), (10, 30), (40, 12), (5, 5), (30, 40)):
+        # the floor point under the pixel centre (the jitter averages F over a footprint a few units wide: F is smooth)
+        s, t = (px_ + 0.5) / w, (py_ + 0.5) / h
+        d = np.array([cam.lower_left[k] + s * cam.horizontal[k] + t * cam.vertical[k] - eye[k] for k in range(3)])
+        if d[1] >= 0:
+            continue
+        tt = -eye[1] / d[1]
+        p = eye + tt * d
+        if x0 - 30 < p[0] < x1 + 30 and z0 - 30 < p[2] < z1 + 30 and False:
+            continue
+        F = form_factor_parallel_rect(p[0], p[2], x0, x1, z0, z1, hgt)
+        expect = rho * le * F
+        got = img[py_, px_, :3].astype(np.float64)
+        assert np.allclose(got, expect, rtol=0.03, atol=1e-4), (px_, py_, got, expect)
+        checked += 1
+    assert checked >= 4
+
+
+def test_russian_roulette_leaves_the_expectation_alone():
+    """raygen.cu:74-82: survival with probability max(T), T /= max(T). With the roulette switched off in the oracle (test
+    hook) paths run to the depth limit instead; the image means must agree within Monte-Carlo error."""
+    w, h, spp = 40, 40, 256
+    blob = abi.build_scene(0, w, h)
+    lib = oracle.load()
+    lib.rtwo_set_debug.argtypes = [C.c_int]
+    lib.rtwo_set_debug.restype = None
+    p = abi.make_params(w, h, spp, 40)
+    on, st_on = oracle.render(blob, p, threads=8)
+    lib.rtwo_set_debug(1)
+    try:
+        off, st_off = oracle.render(blob, p, threads=8)
+    finally:
+        lib.rtwo_set_debug(0)
+    assert st_off.segments > 2 * st_on.segments  # the roulette does cut paths short
+    m_on, m_off = on[..., :3].mean(axis=(0, 1)), off[..., :3].mean(axis=(0, 1))
+    assert np.allclose(m_on, m_off, rtol=0.02), (m_on, m_off)
+    # blocks of the image as well (a bias that cancels in the global mean would show here)
+    b_on = on[..., :3].reshape(4, 10, 4, 10, 3).mean(axis=(1, 3))
+    b_off = off[..., :3].reshape(4, 10, 4, 10, 3).mean(axis=(1, 3))
+    assert np.allclose(b_on, b_off, rtol=0.12, atol=0.01)
+
+
+def test_sanitized_oracle_build_is_clean():
+    """the oracle under AddressSanitizer + UBSan (oracle/Makefile librtw_oracle_asan.so) renders every
+    reference scene and rejects corrupted blobs without a report. Runs in a subprocess (the runtime must be preloaded)."""
+    odir = os.path.join(abi.REPO_DIR, "oracle")
+    subprocess.check_call(["make", "-C", odir, "librtw_oracle_asan.so"], stdout=subprocess.DEVNULL)
+    asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    if not (os.path.isabs(asan) and os.path.exists(asan)):
+        pytest.skip("libasan runtime not found")
+    code = r"""
+import ctypes as C, sys, os
+import numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "tests"))
+from raytracing_weekend_amd import abi
+lib = C.CDLL(os.path.join(%r, "oracle", "librtw_oracle_asan.so"))
+lib.rtwo_render.restype = C.c_int
+lib.rtwo_render.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(abi.Params), C.c_void_p, C.POINTER(abi.Stats), C.c_int]
+for scene in range(5):
+    blob = abi.build_scene(scene, 24, 16)
+    for rng in (0, 1):
+        for est in (0, 1, 2):
+            p = abi.make_params(24, 16, 2, 12, rng_kind=rng, estimator=est)
+            out = np.empty((16, 24, 4), np.float32); st = abi.Stats()
+            assert lib.rtwo_render(blob, len(blob), C.byref(p), out.ctypes.data, C.byref(st), 2) == 0
+            assert np.isfinite(out).all()
+blob = bytearray(abi.build_scene(0, 8, 8))
+rs = np.random.RandomState(3)
+p = abi.make_params(8, 8, 1, 4)
+out = np.empty((8, 8, 4), np.float32)
+for _ in range(300):
+    b = bytearray(blob)
+    for _ in range(rs.randint(1, 6)):
+        b[rs.randint(0, 400)] = rs.randint(0, 256)   # header bytes: counts, offsets, sizes
+    lib.rtwo_render(bytes(b), len(b), C.byref(p), out.ctypes.data, None, 1)   # any status, no memory error
+print("asan-ok")
+""" % (abi.REPO_DIR, abi.REPO_DIR, abi.REPO_DIR)
+    env = dict(os.environ, LD_PRELOAD=asan + (":" + ubsan if os.path.exists(ubsan) else ""), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "asan-ok" in r.stdout, r.stderr[-3000:]
