@@ -158,8 +158,16 @@ typedef struct rtw_pdf {
     int32_t flip;
     float rect[5];   /* p1's hitRectData a0,a1,b0,b1,k                          */
     float bias;
-    float reserved[2];
-} rtw_pdf; /* 48 B */
+} rtw_pdf; /* 40 B */
+
+/* Camera kinds: the reference's scene/camera.cuh:35-56 `cameraType` values (its OptiX-7 path only ever builds type 0,
+ * shaders/camera.cu:11-19; the other two are defined by scene/ioCamera.h:118-179 and never instantiated).
+ *   RTW_CAM_PERSPECTIVE   origin (+ lens offset), direction = lower_left + s*horizontal + t*vertical - origin
+ *   RTW_CAM_ENVIRONMENT   origin; a = (cos(2 pi s) sin(pi t), -cos(pi t), sin(2 pi s) sin(pi t)); direction = normalize(a.x u + a.y v + a.z w)
+ *   RTW_CAM_ORTHOGRAPHIC  origin = lower_left + s*horizontal + t*vertical + camera origin (as camera.cuh:52 states it: the origin
+ *                         enters twice when lower_left is built the way ioOrthographicCamera builds it); direction = -normalize(w)
+ * The two lens draws of the raygen program are consumed whatever the kind. */
+typedef enum rtw_camera_type { RTW_CAM_PERSPECTIVE = 0, RTW_CAM_ENVIRONMENT = 1, RTW_CAM_ORTHOGRAPHIC = 2 } rtw_camera_type;
 
 typedef struct rtw_camera {
     float origin[3];
@@ -184,6 +192,8 @@ typedef struct rtw_scene_header {
     uint32_t texdata_bytes; /* its size; rtw_texture.data counts 4-byte words in it */
     rtw_camera camera;
     rtw_pdf pdf;
+    int32_t camera_type; /* rtw_camera_type (these 8 bytes were rtw_pdf.reserved, always 0, before the cameras of SURVEY 8f rank 4) */
+    uint32_t reserved;
 } rtw_scene_header;
 
 /* Estimators. The default reproduces the reference, including what makes its images

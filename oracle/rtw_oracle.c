@@ -256,6 +256,7 @@ static int scene_open(scene_t* s, const void* blob, size_t bytes) {
     if ((size_t)h->off_textures + (size_t)h->n_textures * sizeof(rtw_texture) > bytes) return RTW_ERR_BAD_SCENE;
     if ((size_t)h->off_lights + (size_t)h->n_lights * sizeof(rtw_light) > bytes) return RTW_ERR_BAD_SCENE;
     if (h->n_xforms < 1) return RTW_ERR_BAD_SCENE;
+    if (h->camera_type < RTW_CAM_PERSPECTIVE || h->camera_type > RTW_CAM_ORTHOGRAPHIC) return RTW_ERR_BAD_SCENE;
     /* include/rtw.h: tables sit at 16-byte aligned offsets (the tables are read in place here) */
     if ((h->off_prims | h->off_xforms | h->off_materials | h->off_textures | h->off_lights | h->off_texdata) & 15u) return RTW_ERR_BAD_SCENE;
     if (((uintptr_t)blob & 3u) != 0) return RTW_ERR_BAD_SCENE;
@@ -793,7 +794,21 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
     }
     v3 dir = vfma(ld3(cam->horizontal), s, ld3(cam->lower_left));
     dir = vfma(ld3(cam->vertical), t, dir);
-    dir = vsub(dir, origin);
+    if (H->camera_type == RTW_CAM_ENVIRONMENT) {
+        /* scene/camera.cuh:35-47: sin / cos of 2 pi s and of pi t = 2 pi (t / 2), by the spec's sincos2pi */
+        float sx, cx, sy, cy;
+        rtwo_sincos2pi(s, &sx, &cx);
+        rtwo_sincos2pi(t * 0.5f, &sy, &cy);
+        v3 a = V(cx * sy, -cy, sx * sy);
+        origin = ld3(cam->origin);
+        dir = normalize3(vfma(ld3(cam->w), a.z, vfma(ld3(cam->v), a.y, vscale(ld3(cam->u), a.x))));
+    } else if (H->camera_type == RTW_CAM_ORTHOGRAPHIC) {
+        /* scene/camera.cuh:49-54 */
+        origin = vadd(dir, ld3(cam->origin));
+        dir = vneg(normalize3(ld3(cam->w)));
+    } else {
+        dir = vsub(dir, origin);
+    }
 
     /* color(): raygen.cu:92-95 */
     if (g.kind == RTW_RNG_TEA_LCG) { g.lcg[1] = g.lcg[0]; g.lcg[2] = g.lcg[0]; }

@@ -27,6 +27,8 @@ PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_RECT_X, PRIM_RECT_Y, PRIM_RECT_Z, PRIM_VOL
 MAT_LAMBERTIAN, MAT_DIFFUSE_LIGHT, MAT_METAL, MAT_DIELECTRIC, MAT_ISOTROPIC, MAT_NORMAL = range(6)
 # rtw_pdf_gen
 RTW_PDF_COSINE, RTW_PDF_MIXTURE_BIAS, RTW_PDF_MIXTURE, RTW_PDF_RECT_X, RTW_PDF_RECT_Y, RTW_PDF_RECT_Z = range(6)
+# rtw_camera_type
+RTW_CAM_PERSPECTIVE, RTW_CAM_ENVIRONMENT, RTW_CAM_ORTHOGRAPHIC = range(3)
 # rtw_texture_type
 TEX_CHECKER, TEX_CONSTANT, TEX_IMAGE, TEX_NOISE, TEX_NULL = range(5)
 
@@ -56,7 +58,7 @@ class Light(C.Structure):
 
 class Pdf(C.Structure):
     _fields_ = [("gen", C.c_int32), ("p0_gen", C.c_int32), ("p1_gen", C.c_int32), ("flip", C.c_int32),
-                ("rect", C.c_float * 5), ("bias", C.c_float), ("reserved", C.c_float * 2)]
+                ("rect", C.c_float * 5), ("bias", C.c_float)]
 
 
 class Camera(C.Structure):
@@ -72,7 +74,7 @@ class SceneHeader(C.Structure):
                 ("off_prims", C.c_uint32), ("off_xforms", C.c_uint32), ("off_materials", C.c_uint32),
                 ("off_textures", C.c_uint32), ("off_lights", C.c_uint32),
                 ("sky_light", C.c_int32), ("off_texdata", C.c_uint32), ("texdata_bytes", C.c_uint32),
-                ("camera", Camera), ("pdf", Pdf)]
+                ("camera", Camera), ("pdf", Pdf), ("camera_type", C.c_int32), ("reserved", C.c_uint32)]
 
 
 class Params(C.Structure):

@@ -236,6 +236,7 @@ struct Rng<RTW_RNG_TEA_LCG> {
     RTW_DEV float randf1() { return xorshift_randf(a); }
     RTW_DEV void align_block() {}
     RTW_DEV void warm() {}
+    RTW_DEV float block_draw(int) const { return 0.f; }  // (Philox only)
     RTW_DEV float rr_draw() { return lcg_rnd(a); }  // raygen.cu:77
     RTW_DEV float ray_time(uint32_t) { return lcg_rnd(b); }
 };
@@ -258,6 +259,8 @@ struct Rng<RTW_RNG_PHILOX> {
         return u24(v);
     }
     RTW_DEV float randf1() { return next1(); }
+    // draw i (a constant) of the block in registers; the caller knows which block that is and advances `a` itself
+    RTW_DEV float block_draw(int i) const { return u24(c[i]); }
     // the closest-hit program of every segment starts at a fresh block (see the oracle): wave-coherent refills
     RTW_DEV void align_block() { a = (a + 3u) & ~3u; seg_base = a; }
     // generate the block the next draw comes from now, while the whole wave is still on one code path
@@ -355,6 +358,7 @@ struct DScene {
     float bmin[3], bmax[3];                  // generous world bounds of everything (k_first's wave-uniform miss test)
     rtw_camera cam;
     rtw_pdf pdf;
+    int32_t cam_type;                        // rtw_camera_type
 };
 
 RTW_DEV bool is_volume(int type) { return type == RTW_PRIM_VOLUME_BOX || type == RTW_PRIM_VOLUME_SPHERE; }

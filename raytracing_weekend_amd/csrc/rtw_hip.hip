@@ -365,6 +365,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         !in_range(h.off_materials, h.n_materials, sizeof(rtw_material)) || !in_range(h.off_textures, h.n_textures, sizeof(rtw_texture)) ||
         !in_range(h.off_lights, h.n_lights, sizeof(rtw_light)) || h.n_xforms < 1)
         return fail(c, RTW_ERR_BAD_SCENE, "scene table out of range");
+    if (h.camera_type < RTW_CAM_PERSPECTIVE || h.camera_type > RTW_CAM_ORTHOGRAPHIC) return fail(c, RTW_ERR_BAD_SCENE, "unknown camera type");
     if ((h.off_prims | h.off_xforms | h.off_materials | h.off_textures | h.off_lights | h.off_texdata) & 15u)
         return fail(c, RTW_ERR_BAD_SCENE, "scene table not 16-byte aligned");
     const char* b = (const char*)blob;
@@ -639,6 +640,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.has_motion = has_motion;
     sc.cam = h.camera;
     sc.pdf = h.pdf;
+    sc.cam_type = h.camera_type;
     // LDS per block: the traversal stacks, then as many leading (breadth-first) tree nodes as fit the budget
     c->stack_depth = use_bvh ? bvh.max_depth + 2 : 0;
     sc.stack_depth = c->stack_depth;

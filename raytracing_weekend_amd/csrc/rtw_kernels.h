@@ -215,8 +215,16 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
             v = normalize3(cross3(w, a));
             u = cross3(w, v);
         }
-        float r1 = g.next1();
-        float r2 = g.next1();
+        float r1, r2;
+        if (KIND == RTW_RNG_PHILOX) {
+            // the segment's first block is in registers (align_block + warm above) and these are its draws 0 and 1: no
+            // block check, no lane select (every next1() call site otherwise carries its own copy of the refill)
+            r1 = g.block_draw(0); r2 = g.block_draw(1);
+            g.a += 2u;
+        } else {
+            r1 = g.next1();
+            r2 = g.next1();
+        }
         float sn, cs;
         sincos2pi(r1, sn, cs);
         float sq = __builtin_sqrtf(r2);
@@ -355,8 +363,15 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         v3 ldir = V(0.f, 0.f, 0.f), lem = V(0.f, 0.f, 0.f);
         if (gen == RTW_PDF_RECT_X || gen == RTW_PDF_RECT_Y || gen == RTW_PDF_RECT_Z) {
             // rectPdf.cu:124-193
-            float ra = g.next1();
-            float rb = g.next1();
+            float ra, rb;
+            if (KIND == RTW_RNG_PHILOX && nl == 1) {
+                // only a Lambertian vertex gets here, two draws into its block: these are draws 2 and 3 of the same block
+                ra = g.block_draw(2); rb = g.block_draw(3);
+                g.a += 2u;
+            } else {
+                ra = g.next1();
+                rb = g.next1();
+            }
             float pa = fma_(ra, sc.pdf.rect[1] - sc.pdf.rect[0], sc.pdf.rect[0]);
             float pb = fma_(rb, sc.pdf.rect[3] - sc.pdf.rect[2], sc.pdf.rect[2]);
             float k = sc.pdf.rect[4];
@@ -553,7 +568,19 @@ RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const ui
     }
     p.d = vfma(ld3(cam.horizontal), s, ld3(cam.lower_left));
     p.d = vfma(ld3(cam.vertical), t, p.d);
-    p.d = vsub(p.d, p.o);
+    if (A.sc.cam_type == RTW_CAM_ENVIRONMENT) {  // scene/camera.cuh:35-47 (pi t = 2 pi (t / 2))
+        float sx, cx, sy, cy;
+        sincos2pi(s, sx, cx);
+        sincos2pi(t * 0.5f, sy, cy);
+        const v3 a = V(cx * sy, -cy, sx * sy);
+        p.o = ld3(cam.origin);
+        p.d = normalize3(vfma(ld3(cam.w), a.z, vfma(ld3(cam.v), a.y, vscale(ld3(cam.u), a.x))));
+    } else if (A.sc.cam_type == RTW_CAM_ORTHOGRAPHIC) {  // scene/camera.cuh:49-54
+        p.o = vadd(p.d, ld3(cam.origin));
+        p.d = vneg(normalize3(ld3(cam.w)));
+    } else {
+        p.d = vsub(p.d, p.o);
+    }
     p.gk = (uint32_t)(r4 * 16777216.0f);
     p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(0u) : 0.0f;  // raygen.cu:48
     p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;

@@ -41,6 +41,7 @@ void Director::destroy() {
 void Director::createScene(unsigned int sceneNumber) {
     int error = m_scene.init(m_Nx, m_Ny, m_Ns, m_maxRayDepth, static_cast<int>(sceneNumber));
     if (error) std::exit(EXIT_FAILURE);  // Director.cpp:954-958
+    m_scene.setCameraKind(m_cameraKind);
     marshalAndUpload();
     if (_verbose) std::cerr << "INFO: Scene description: " << m_scene.getDescription() << std::endl;
 }

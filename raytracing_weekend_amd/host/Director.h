@@ -34,6 +34,7 @@ public:
     // (rtw_create with n_devices = n) and gathered on the first device; the image does not depend on n
     void setDevices(int n, int first = 0, bool same = false) { m_devices.clear(); for (int i = 0; i < n; i++) m_devices.push_back(same ? first : first + i); }
     void setEstimator(int estimator) { m_estimator = estimator; }  // rtw_estimator
+    void setCameraKind(int kind) { m_cameraKind = kind; }          // rtw_camera_type (the reference only ever builds the perspective one)
     // the reference's renderFrame ends with the OptiX AI denoiser (Director.cpp:986-997); iterations > 0 runs the
     // a-trous stand-in (rtw_denoise) on the frame instead
     void setDenoise(int iterations, float sigma) { m_denoiseIterations = iterations; m_denoiseSigma = sigma; }
@@ -49,6 +50,7 @@ private:
     int m_rngKind = RTW_RNG_PHILOX;
     std::vector<int> m_devices{0};
     int m_estimator = RTW_EST_REFERENCE;
+    int m_cameraKind = RTW_CAM_PERSPECTIVE;
     int m_denoiseIterations = 0;
     float m_denoiseSigma = 0.5f;
     rtw_ctx* m_ctx = nullptr;

@@ -72,6 +72,7 @@ inline std::vector<uint8_t> marshalScene(const ioScene& sc) {
     put(h.camera.origin, o); put(h.camera.u, u); put(h.camera.v, v); put(h.camera.w, w);
     put(h.camera.lower_left, llc); put(h.camera.horizontal, hor); put(h.camera.vertical, ver);
     h.camera.lens_radius = 0.f;
+    h.camera_type = sc.camera->cameraType();
     h.camera.time0 = 0.f;
     h.camera.time1 = 1.f;
 

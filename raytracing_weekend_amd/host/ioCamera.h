@@ -1,6 +1,6 @@
-// ioCamera.h — host camera description. Mirrors scene/ioCamera.h:10-116 of the reference
-// (ioCamera base + ioPerspectiveCamera; the environment/orthographic cameras are never
-// instantiated by the reference and are out of scope). All math in float, like the reference.
+// ioCamera.h — host camera description. Mirrors scene/ioCamera.h:10-179 of the reference: ioCamera base,
+// ioPerspectiveCamera (the only one the reference instantiates), ioEnvironmentCamera and ioOrthographicCamera
+// (defined there, never built; their ray generation is scene/camera.cuh:35-56). All math in float, like the reference.
 #pragma once
 #include <cmath>
 
@@ -34,6 +34,9 @@ public:
         m_time1 = t1;
     }
     virtual ~ioCamera() {}
+    // what Director::initLaunchParams would put into SysParamter (sysparameter.h:44-54) + the camera kind
+    virtual int cameraType() const = 0;
+    virtual void getfrustum(Float3& pos, Float3& u, Float3& v, Float3& w, Float3& leftCorner, Float3& horizontal, Float3& vertical) const = 0;
 
     Float3 m_origin, m_u, m_v, m_w;
     float m_time0, m_time1;
@@ -55,13 +58,47 @@ public:
         m_vertical = (2.0f * halfHeight * focus_dist) * m_v;
     }
 
+    int cameraType() const override { return RTW_CAM_PERSPECTIVE; }
     void getfrustum(Float3& pos, Float3& u, Float3& v, Float3& w, Float3& leftCorner, Float3& horizontal,
-                    Float3& vertical) const {
+                    Float3& vertical) const override {
         pos = m_origin; u = m_u; v = m_v; w = m_w;
         leftCorner = m_lowerLeftCorner; horizontal = m_horizontal; vertical = m_vertical;
     }
 
 private:
+    Float3 m_lowerLeftCorner, m_horizontal, m_vertical;
+};
+
+// scene/ioCamera.h:118-139: position and frame only; rays cover the whole sphere of directions (camera.cuh:35-47)
+class ioEnvironmentCamera : public ioCamera {
+public:
+    ioEnvironmentCamera(float fromX, float fromY, float fromZ, float toX, float toY, float toZ, float upX, float upY, float upZ,
+                        float t0 = 0.f, float t1 = 0.f)
+        : ioCamera(fromX, fromY, fromZ, toX, toY, toZ, upX, upY, upZ, t0, t1) {}
+    int cameraType() const override { return RTW_CAM_ENVIRONMENT; }
+    void getfrustum(Float3& pos, Float3& u, Float3& v, Float3& w, Float3& leftCorner, Float3& horizontal, Float3& vertical) const override {
+        pos = m_origin; u = m_u; v = m_v; w = m_w;
+        leftCorner = make_float3(0.f, 0.f, 0.f); horizontal = leftCorner; vertical = leftCorner;
+    }
+};
+
+// scene/ioCamera.h:141-178: a height x width window through the camera position; parallel rays along -w (camera.cuh:49-54)
+class ioOrthographicCamera : public ioCamera {
+public:
+    ioOrthographicCamera(float fromX, float fromY, float fromZ, float toX, float toY, float toZ, float upX, float upY, float upZ,
+                         float height, float width, float t0 = 0.f, float t1 = 0.f)
+        : ioCamera(fromX, fromY, fromZ, toX, toY, toZ, upX, upY, upZ, t0, t1) {
+        float halfHeight = height / 2.0f;
+        float halfWidth = width / 2.0f;
+        m_lowerLeftCorner = m_origin - halfWidth * m_u - halfHeight * m_v - m_w;
+        m_horizontal = (2.0f * halfWidth) * m_u;
+        m_vertical = (2.0f * halfHeight) * m_v;
+    }
+    int cameraType() const override { return RTW_CAM_ORTHOGRAPHIC; }
+    void getfrustum(Float3& pos, Float3& u, Float3& v, Float3& w, Float3& leftCorner, Float3& horizontal, Float3& vertical) const override {
+        pos = m_origin; u = m_u; v = m_v; w = m_w;
+        leftCorner = m_lowerLeftCorner; horizontal = m_horizontal; vertical = m_vertical;
+    }
     Float3 m_lowerLeftCorner, m_horizontal, m_vertical;
 };
 

@@ -3,6 +3,9 @@
 // but every class only fills the pointer-free records of include/rtw.h; there is no OptiX
 // accel build here (the library builds its own BVH in rtw_upload_scene).
 #pragma once
+#include <iterator>
+
+#include "JpegDecode.h"
 #include <cctype>
 #include <cmath>
 #include <cstring>
@@ -186,8 +189,8 @@ struct ioNoiseTexture : ioTexture {
     }
     float scale;
 };
-// ioTexture.h:225-338. The reference decodes assets/earthmap.jpg with stb_image; this host reads binary or ASCII
-// PPM (P6 / P3, 8 bit) and nothing else. Rows are flipped like ioTexture.h:247-250, alpha is 255.
+// ioTexture.h:225-338. The reference decodes assets/earthmap.jpg with stb_image; this host reads baseline JPEG with its
+// own decoder (JpegDecode.h) and binary or ASCII PPM (P6 / P3, 8 bit). Rows are flipped like ioTexture.h:247-250, alpha is 255.
 struct ioImageTexture : ioTexture {
     explicit ioImageTexture(const std::string& fileName) { load(fileName); }
     int32_t emit(TexEmit& e) const override {
@@ -207,6 +210,14 @@ private:
     void load(const std::string& fileName) {
         std::ifstream f(fileName, std::ios::binary);
         if (!f) throw std::runtime_error("image texture: cannot open " + fileName);
+        std::vector<unsigned char> rgb;
+        if (f.peek() == 0xFF) {  // JPEG (SOI = FF D8)
+            std::vector<uint8_t> file((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+            std::string err;
+            if (!decodeJpeg(file.data(), file.size(), nx, ny, rgb, err)) throw std::runtime_error("image texture: " + fileName + ": " + err);
+            pack(rgb);
+            return;
+        }
         auto token = [&]() {  // PNM header token, '#' comments skipped
             std::string tok;
             int ch;
@@ -223,7 +234,7 @@ private:
         try { nx = std::stoi(token()); ny = std::stoi(token()); maxv = std::stoi(token()); }
         catch (const std::exception&) { throw std::runtime_error("image texture: bad PPM header in " + fileName); }
         if (nx <= 0 || ny <= 0 || nx > 32768 || ny > 32768 || maxv != 255) throw std::runtime_error("image texture: unsupported PPM (size or maxval) " + fileName);
-        std::vector<unsigned char> rgb(static_cast<size_t>(nx) * ny * 3);
+        rgb.resize(static_cast<size_t>(nx) * ny * 3);
         if (magic == "P6") {
             f.read(reinterpret_cast<char*>(rgb.data()), static_cast<std::streamsize>(rgb.size()));
             if (static_cast<size_t>(f.gcount()) != rgb.size()) throw std::runtime_error("image texture: truncated PPM " + fileName);
@@ -234,6 +245,9 @@ private:
                 rgb[i] = static_cast<unsigned char>(std::stoi(t));
             }
         }
+        pack(rgb);
+    }
+    void pack(const std::vector<unsigned char>& rgb) {  // ioTexture.h:244-262
         texels.resize(static_cast<size_t>(nx) * ny);
         for (int i = 0; i < nx; ++i)
             for (int j = 0; j < ny; ++j) {

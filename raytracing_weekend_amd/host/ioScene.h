@@ -5,7 +5,8 @@
 //   3 VolumesCornellBox   (ioScene.h:630-788)   Cornell box with two participating media
 //   4 TheNextWeekFinal    (ioScene.h:791-982)   400 ground boxes, 1000-sphere cluster under a transform, two media,
 //                                               noise / image textures, a moving sphere (3410 primitives)
-// Scenes 2 and 4 load assets/earthmap.ppm (see assetPath); the reference decodes assets/earthmap.jpg with stb_image.
+// Scenes 2 and 4 load assets/earthmap.jpg where one is installed (the reference's asset, decoded by JpegDecode.h), else the
+// synthetic assets/earthmap.ppm of this tree (see earthMapPath).
 // Primitive i, material i and instance i line up, as the reference relies on
 // (geometryList.size()==materialList.size(), ioScene.h:262,426,581).
 #pragma once
@@ -64,6 +65,12 @@ inline std::string assetPath(const std::string& name) {
     }
     return dirs.back() + "/" + name;  // reported in the error message of the loader
 }
+// the reference's earth map (assets/earthmap.jpg, ioScene.h:438,911) where it is installed, else the synthetic PPM this tree ships
+inline std::string earthMapPath() {
+    const std::string jpg = assetPath("earthmap.jpg");
+    if (std::ifstream(jpg).good()) return jpg;
+    return assetPath("earthmap.ppm");
+}
 
 class ioScene {
 public:
@@ -103,7 +110,26 @@ public:
     std::vector<ioGeometryInstance> geoInstList;
     std::vector<rtw_light> m_lightDefinitions;
     pdfCallfun_host MCpdf;
-    std::unique_ptr<ioPerspectiveCamera> camera;
+    std::unique_ptr<ioCamera> camera;
+    // swap the scene's perspective camera for one of the reference's two unused kinds at the same position
+    // and frame. The orthographic window is the perspective image plane (its extent at the focus distance), and - because
+    // scene/camera.cuh:52 adds the camera origin to a corner that already contains it - the frame is re-centred on the origin
+    // (position 0) so that the window looks at the scene; kind: rtw_camera_type.
+    void setCameraKind(int kind) {
+        if (!camera || kind == RTW_CAM_PERSPECTIVE) return;
+        Float3 o, u, v, w, llc, hor, ver;
+        camera->getfrustum(o, u, v, w, llc, hor, ver);
+        const Float3 at = o - w, up = v;
+        if (kind == RTW_CAM_ENVIRONMENT) {
+            camera.reset(new ioEnvironmentCamera(o.x, o.y, o.z, at.x, at.y, at.z, up.x, up.y, up.z, camera->m_time0, camera->m_time1));
+        } else if (kind == RTW_CAM_ORTHOGRAPHIC) {
+            std::unique_ptr<ioOrthographicCamera> oc(new ioOrthographicCamera(o.x, o.y, o.z, at.x, at.y, at.z, up.x, up.y, up.z, length(ver), length(hor),
+                                                                              camera->m_time0, camera->m_time1));
+            // corner relative to the position; the device adds the position back (camera.cuh:52)
+            oc->m_lowerLeftCorner = oc->m_lowerLeftCorner - oc->m_origin;
+            camera = std::move(oc);
+        }
+    }
 
 private:
     // ioScene.h:103-148
@@ -279,7 +305,7 @@ private:
         sceneDescription = "IOW Scene with a light box";
         const ioTexture* constantGrey = tex(new ioConstantTexture(make_float3(0.7f, 0.7f, 0.7f)));
         const ioTexture* noise1 = tex(new ioNoiseTexture(1.f));
-        const ioTexture* earthGlobeImage = tex(new ioImageTexture(assetPath("earthmap.ppm")));
+        const ioTexture* earthGlobeImage = tex(new ioImageTexture(earthMapPath()));
         const ioTexture* light16 = tex(new ioConstantTexture(make_float3(16.f, 16.f, 16.f)));
 
         geometryList.emplace_back(new ioSphere(0.0f, -1000.0f, 0.0f, 1000.0f));  // big sphere, Perlin ground
@@ -307,7 +333,7 @@ private:
         const ioTexture* groundGreenish = tex(new ioConstantTexture(make_float3(0.48f, 0.83f, 0.53f)));
         const ioTexture* metal1 = tex(new ioConstantTexture(make_float3(0.8f, 0.8f, 0.9f)));
         const ioTexture* noisep1 = tex(new ioNoiseTexture(0.1f));
-        const ioTexture* earthGlobeImage = tex(new ioImageTexture(assetPath("earthmap.ppm")));
+        const ioTexture* earthGlobeImage = tex(new ioImageTexture(earthMapPath()));
         const ioTexture* light7 = tex(new ioConstantTexture(make_float3(7.f, 7.f, 7.f)));
         uint32_t seed = 0x6314759;
         const ioMaterial* glassyBlueFog = mat(new ioIsotropicMaterial(tex(new ioConstantTexture(make_float3(0.2f, 0.4f, 0.9f)))));

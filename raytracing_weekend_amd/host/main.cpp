@@ -61,6 +61,7 @@ int main(int argc, char* argv[]) {
     -denoise N     N passes (1..8) of the a-trous filter that stands in for the reference's AI denoiser (default: off)
     -est K         reference (default: the reference's estimator, quirks included), corrected, or brute
                    (corrected without light sampling)
+    -cam K         perspective (default), environment or orthographic (the reference's two unused camera kinds, scene/ioCamera.h:118-179)
     -gpu N         Device ordinal (the first one with -gpus)
     -gpus N        Render on N GPUs of this node: interleaved row shards, one gather onto the first device (default 1)
     -o FILE        Write FILE instead of ASCII P3 on stdout: *.ppm = binary P6, *.png = 8-bit PNG, *.pfm = linear float PFM
@@ -100,7 +101,14 @@ int main(int argc, char* argv[]) {
     else if (estName == "brute") estimator = RTW_EST_CORRECTED_NO_NEE;
     else if (!estName.empty() && estName != "reference") std::cerr << "WARNING: unknown -est " << estName << ", using reference" << std::endl;
 
+    int camKind = RTW_CAM_PERSPECTIVE;
+    const std::string& camName = cl_input.getCmdOption("-cam");
+    if (camName == "environment") camKind = RTW_CAM_ENVIRONMENT;
+    else if (camName == "orthographic") camKind = RTW_CAM_ORTHOGRAPHIC;
+    else if (!camName.empty() && camName != "perspective") std::cerr << "WARNING: unknown -cam " << camName << ", using perspective" << std::endl;
+
     Director director(Qverbose, Qdebug);
+    director.setCameraKind(camKind);
     // RTW_SAME_DEVICE=1 (tests on a one-GPU box): all -gpus N shards render on device -gpu
     if (gpus > 1) director.setDevices(gpus, gpu, std::getenv("RTW_SAME_DEVICE") != nullptr);
     else director.setDevice(gpu);

@@ -174,6 +174,26 @@ def test_tree_whose_root_is_a_leaf(gpu, monkeypatch, n_rects, n_volumes, brute_m
     gpu.upload_scene(abi.build_scene(0, 16, 16))
 
 
+@pytest.mark.parametrize("scene", [100, 200, 101, 204])
+def test_environment_and_orthographic_cameras(gpu, scene):
+    """the reference's two unused camera kinds (scene/ioCamera.h:118-179, scene/camera.cuh:35-56) through
+    the C++ host description (scene + 100 * kind) and the blob's camera_type, GPU vs oracle, both generators, both pipelines'
+    raygen (k_path on the small scenes, k_first on the trees)."""
+    w, h = 96, 64
+    blob = abi.build_scene(scene, w, h)
+    assert abi.parse_scene(blob)["header"].camera_type == scene // 100
+    gpu.upload_scene(blob)
+    for rng in (abi.RTW_RNG_PHILOX, abi.RTW_RNG_TEA_LCG):
+        p = abi.make_params(w, h, 4, 16, rng_kind=rng)
+        img, st = gpu.render(p)
+        ref, st_ref = oracle.render(blob, p, threads=16)
+        check(img, ref, st, st_ref)
+    if scene != 200:  # (the small orthographic window of the Cornell box looks straight at the mirror box, which shows the dark outside)
+        assert img[..., :3].max() > 0
+    pers, _ = oracle.render(abi.build_scene(scene % 100, w, h), abi.make_params(w, h, 4, 16, rng_kind=rng), threads=16)
+    assert not np.array_equal(pers, ref)
+
+
 @pytest.mark.parametrize("ids", [[0, 0], [0, 0, 0]])
 def test_in_library_multi_device_render_is_the_single_device_image(gpu, ids):
     """rtw_create(n_devices = N): N interleaved shards rendered from N host threads, gathered on device_ids[0]; with every

