@@ -1,20 +1,27 @@
-// rtw_hip.hip — wavefront Monte-Carlo path tracer for MI355X (gfx950) behind the C ABI of include/rtw.h.
+// rtw_hip.hip — Monte-Carlo path tracer for MI355X (gfx950) behind the C ABI of include/rtw.h.
 //
 // What the reference does in ONE OptiX megakernel launch (Director.cpp:982-984: raygen -> traverse ->
-// closest-hit/miss -> callables, one thread per pixel, one sample) is done here as a wavefront loop over
-// batches of S samples per pixel (P = pixels*S paths in flight, sized for HBM, not for cache):
+// closest-hit/miss -> callables, one thread per pixel, one sample) is done here by one of two pipelines:
 //
-//   k_first                     primary rays, their closest hit and closest-hit program (light sample queued)
-//   repeat for the wide bounces (1..5; 1..19 in tree scenes):
-//     k_trace / k_trace_bvh     radiance ray + queued shadow probe of every surviving path, surfaces only
-//     k_shade                   (volume pass,) material scatter, light sample (shadow probe queued), roulette, compaction
-//   k_bounce x few              thin tail: several fused bounces per launch, in registers
-//   two batches are in flight on two streams ("lanes"); the resolves stay ordered on the caller's stream
-//   k_resolve                   sums the S sample slots of each pixel in sample order (deterministic)
-//   k_finish (once)             mean radiance -> float4 framebuffer tile
+//   k_path (scenes walked with the candidate lists: <= 24 primitives)
+//     one persistent launch per pass over the samples: whole paths in registers, a lane owns a (pixel, 64-sample block)
+//     unit, regenerates camera rays as its paths end and stores one 16-byte sum per block; k_resolve_blocks adds the
+//     block sums per pixel in order
+//
+//   wavefront kernels (tree scenes), batches of S samples per pixel, P = pixels*S paths in flight in HBM:
+//     k_first                     primary rays, their closest hit and closest-hit program (light sample queued)
+//     repeat for the wide bounces (1..19):
+//       k_trace_bvh               radiance ray + queued shadow probe of every surviving path, surfaces only
+//       k_shade                   (volume pass,) material scatter, light sample (probe queued), roulette, compaction
+//     k_bounce x few              thin tail: several fused bounces per launch, in registers
+//     two batches are in flight on two streams ("lanes"); the resolves stay ordered on the caller's stream
+//     k_resolve                   sums the S sample slots of each pixel in the spec's blocked order (deterministic)
+//
+//   k_finish (once)               mean radiance -> float4 framebuffer tile
+//   n_devices > 1: one host thread + context per device, interleaved row shards, peer-copy gather, k_interleave
 //
 // No OptiX, no CUDA shims, no Triton, no MFMA (divergent scalar fp32). Results do not depend on
-// scheduling: every path owns a counter-based RNG stream and its own radiance slot.
+// scheduling: every path owns a counter-based RNG stream and every (pixel, block) its own sum.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

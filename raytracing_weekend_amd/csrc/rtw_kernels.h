@@ -1,15 +1,17 @@
-// rtw_kernels.h — the wavefront kernels (gfx950). See rtw_hip.hip for the launch schedule.
+// rtw_kernels.h — the kernels (gfx950). See rtw_hip.hip for the two pipelines and their launch schedules.
 //
+//   k_path       small scenes: whole paths in registers, lanes own (pixel, sample block) units and regenerate; LDS candidate
+//                lists and hit records; only 16-byte unit sums reach HBM
+//   k_path_tree  the same for tree scenes, lanes vote on the kind of step (built, slower than the wavefront kernels, off)
 //   k_first      generate primary rays (raygen.cu:123-147, camera.cu:11-19), trace and shade the primary segment
 //   k_shade      closest-hit / miss programs for one bounce of every live path: (media: the volume pass), material
 //                scatter, texture, light sampling (the shadow ray is QUEUED in the path state, not traced), Russian
 //                roulette, wave64 ballot/popcount compaction of the survivors into the workgroup's own output region
-//   k_trace<>    surfaces only, small scenes: the radiance ray's closest hit and the queued shadow ray's any-hit in one
-//                shared walk over the scalar-cache candidate lists (or one traverse<> each with moving spheres)
+//   k_trace<>    surfaces only, small scenes under RTW_PATH=0: the radiance ray's closest hit and the queued shadow ray's
+//                any-hit in one shared walk over the scalar-cache candidate lists (or one traverse<> each with moving spheres)
 //   k_trace_bvh  surfaces only, tree scenes: waves own streams of chunks, idle lanes refill, majority-vote stepping
 //   k_bounce     fused trace+shade(+inline shadow probe) for several bounces in registers: the thin tail of a batch
-//                (latency-bound launches); every bounce with RTW_FUSED=1 / RTW_SPLIT_MEDIA=0
-//   k_resolve / k_finish   deterministic per-pixel sum of the sample slots, mean radiance
+//   k_resolve / k_resolve_blocks / k_finish   deterministic per-pixel sums in the spec's blocked order, mean radiance
 //
 // Path state: six 16-byte SoA planes per path (96 B), read and written with dwordx4 accesses that
 // are contiguous across a wave:
