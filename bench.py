@@ -89,8 +89,12 @@ def main():
     dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    if world > 1:
+    # RTW_BENCH_FORCE_DIST=1: open the process group and run the gather even at world size 1 (a rehearsal of the RCCL path on a
+    # one-GPU box: two ranks cannot share a device under RCCL, one rank can still initialise it and gather to itself)
+    use_dist = world > 1 or os.environ.get("RTW_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -108,9 +112,9 @@ def main():
     r = abi.Renderer(dev_index)
     r.upload_scene(blob)
     tile = torch.zeros((max_rows, WIDTH, 4), dtype=torch.float32, device=dev)
-    host_gather = world > 1 and args.backend != "nccl"
+    host_gather = use_dist and args.backend != "nccl"
     gdev = torch.device("cpu") if host_gather else dev
-    gathered = [torch.empty((max_rows, WIDTH, 4), dtype=torch.float32, device=gdev) for _ in range(world)] if (world > 1 and rank == 0) else None
+    gathered = [torch.empty((max_rows, WIDTH, 4), dtype=torch.float32, device=gdev) for _ in range(world)] if (use_dist and rank == 0) else None
     # a stream of our own: handle 0 (torch's default stream) would select the library's private stream (include/rtw.h)
     tstream = torch.cuda.Stream(dev)
     tstream.wait_stream(torch.cuda.current_stream(dev))
@@ -118,13 +122,13 @@ def main():
 
     def step():
         st = r.render_device(params, tile.data_ptr(), stream)
-        if world > 1:
+        if use_dist:
             # the one collective: row tiles -> rank 0 (RCCL over xGMI; through host memory in the gloo rehearsal)
             dist.gather(tile.cpu() if host_gather else tile, gathered, dst=0)
         return st
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -143,7 +147,7 @@ def main():
                         float(sum(s.shadow_rays for s in stats))], dtype=torch.float64, device=dev)
     kt = torch.tensor([sum(s.bounce_seconds for s in stats), float(sum(s.bounce_launches for s in stats)),
                        sum(s.seconds for s in stats)], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
     dt_max = float(t.item())
@@ -152,7 +156,7 @@ def main():
     if args.check and rank == 0:
         full = torch.empty((HEIGHT, WIDTH, 4), dtype=torch.float32)
         for g in range(world):
-            full[g::world] = (gathered[g] if world > 1 else tile)[: n_rows[g]].cpu()
+            full[g::world] = (gathered[g] if use_dist else tile)[: n_rows[g]].cpu()
         alone = torch.zeros((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev)
         r.render_device(abi.make_params(WIDTH, HEIGHT, args.spp, DEPTH, seed=SEED, rng_kind=args.rng), alone.data_ptr(), stream)
         torch.cuda.synchronize(dev)
@@ -254,7 +258,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(blob, abi)
         print(json.dumps(line), flush=True)
     r.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -480,6 +480,20 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
 
 
+def test_bench_rccl_path_at_world_size_one():
+    """The RCCL leg of bench.py (init_process_group("nccl", device_id=...), the gather of device tensors, barrier, all_reduce)
+    executed for real: RCCL refuses two ranks on one GPU ("Duplicate GPU detected"), but one rank can open the communicator
+    and gather to itself. --check compares the gathered frame with a render of its own."""
+    import subprocess, sys, json
+    env = dict(os.environ, RTW_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--spp", "32", "--check",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0
+
+
 def test_cli_director_outputs(tmp_path):
     """The C++ host surface end to end (main -> InputParser -> Director -> C ABI): the PFM it writes is the oracle's
     image bit for bit, the binary P6 and the reference-style ASCII P3 on stdout carry the same 8-bit pixels."""
