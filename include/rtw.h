@@ -40,8 +40,9 @@ extern "C" {
 /* Summation order of a pixel's samples (part of the arithmetic contract): the samples of a render call are
  * summed in ascending order inside aligned blocks of RTW_SUM_BLOCK samples (counted from sample_offset), and the block
  * sums are added in ascending order; the mean is that sum divided by spp. The reference renders one sample per launch
- * (raygen.cu:123-159) and so defines no order; blocks let a lane own a pixel's block in registers. */
-#define RTW_SUM_BLOCK 64
+ * (raygen.cu:123-159) and so defines no order; blocks let a lane own a run of a pixel's samples in registers, and a small
+ * block lets the last few percent of a render be handed out in short pieces (a launch ends when its slowest piece ends). */
+#define RTW_SUM_BLOCK 16
 
 typedef enum rtw_status {
     RTW_OK = 0,

@@ -74,7 +74,10 @@ struct rtw_ctx {
     size_t accum_pix = 0;
     float4* blocksum = nullptr;  // k_path: [block][pixel] unit sums of one pass
     size_t blocksum_elems = 0;
-    uint32_t* d_queue = nullptr; // k_path: job counter
+    uint32_t* d_queue = nullptr; // k_path: job counter [0], k_classify's two counters [1], [2]
+    uint32_t* d_order = nullptr; // k_path: job order of the pixel groups
+    hipStream_t stream2 = nullptr;  // k_path: the stream of the fine-grained end-game launch
+    size_t order_groups = 0;
     std::vector<hipEvent_t> ev_pool;  // timing events, reused across launches and calls
     unsigned long long* d_stats = nullptr;
     float4* d_out = nullptr;
@@ -195,7 +198,9 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //                   regeneration); 0: always the wavefront pipeline
 //   RTW_PATH_TREE   1: tree scenes render through k_path_tree (k_path's idea with a per-lane walk state machine and a vote on the
 //                   kind of step; bit-identical, measured 25-45 % slower than the wavefront kernels on scenes 1, 2, 4); 0 (default): wavefront
-//   RTW_PATH_JOB_BLOCKS  sample blocks per k_path job (default 2: a job is 64 pixels x 128 samples)
+//   RTW_PATH_UNIT_BLOCKS 16-sample blocks a lane takes as one unit in the bulk launch (default 4: 64 samples)
+//   RTW_PATH_FINE_BLOCKS blocks at the end of a pass that a second, concurrent launch hands out one by one (default 8: 128 samples)
+//   RTW_PATH_JOB_BLOCKS  units per pixel in one k_path job (default 2: a job is 64 pixels x 2 units)
 //   RTW_PATH_GRID_MULT   k_path workgroups per CU (default: what the occupancy query admits)
 //   RTW_BLOCKSUM_BYTES   cap of the k_path block-sum buffer (default 16 GiB); larger renders run in passes over the samples
 //   RTW_KERNEL_TIMING    0: no per-launch events even when the caller asks for rtw_stats (kernel_seconds stay 0)
@@ -213,6 +218,8 @@ struct Tuning {
     int path = 1;
     int path_tree = 0;
     int path_job_blocks = 2;
+    int path_unit_blocks = 4;
+    int path_fine_blocks = 8;
     int path_grid_mult = 0;
     size_t blocksum_bytes = (size_t)16 << 30;
     bool kernel_timing = true;
@@ -239,6 +246,8 @@ Tuning read_tuning() {
     if (geti("RTW_PATH", v)) t.path = (int)std::max<long long>(0, std::min<long long>(2, v));
     if (geti("RTW_PATH_TREE", v)) t.path_tree = v != 0;
     if (geti("RTW_PATH_JOB_BLOCKS", v)) t.path_job_blocks = (int)std::max<long long>(1, std::min<long long>(1024, v));
+    if (geti("RTW_PATH_UNIT_BLOCKS", v)) t.path_unit_blocks = (int)std::max<long long>(1, std::min<long long>(4096, v));
+    if (geti("RTW_PATH_FINE_BLOCKS", v)) t.path_fine_blocks = (int)std::max<long long>(0, std::min<long long>(4096, v));
     if (geti("RTW_PATH_GRID_MULT", v)) t.path_grid_mult = (int)std::max<long long>(1, std::min<long long>(16, v));
     if (geti("RTW_BLOCKSUM_BYTES", v) && v >= (1 << 16)) t.blocksum_bytes = (size_t)v;
     if (geti("RTW_KERNEL_TIMING", v)) t.kernel_timing = v != 0;
@@ -342,6 +351,8 @@ int rtw_destroy(rtw_ctx* c) {
     if (c->part) (void)hipFree(c->part);
     if (c->blocksum) (void)hipFree(c->blocksum);
     if (c->d_queue) (void)hipFree(c->d_queue);
+    if (c->d_order) (void)hipFree(c->d_order);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     if (c->stage) (void)hipFree(c->stage);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_out) (void)hipFree(c->d_out);
@@ -780,27 +791,67 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
 #undef RTW_OCC
             wg_per_cu = (qe == hipSuccess && nb > 0) ? std::min(nb, 8) : 4;
         }
+        const size_t n_groups = (npix + 63) / 64;
+        if (n_groups > c->order_groups) {
+            if (c->d_order) (void)hipFree(c->d_order);
+            c->d_order = nullptr; c->order_groups = 0;
+            HIP_TRY(c, hipMalloc(&c->d_order, 3 * n_groups * sizeof(uint32_t)));
+            c->order_groups = n_groups;
+        }
+        if (!c->stream2) HIP_TRY(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
         HIP_TRY_C(hipEventRecord(ev_begin, s));
         HIP_TRY_C(hipMemsetAsync(c->accum, 0, npix * sizeof(float4), s));
         HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, (kStatRows + 1) * 8 * sizeof(unsigned long long), s));
-        const size_t n_groups = (npix + 63) / 64;
+        {   // job order: longest units first (k_classify)
+            HIP_TRY_C(hipMemsetAsync(c->d_queue, 0, 64, s));
+            KArgs a = base;
+            const dim3 cg((unsigned)std::min<size_t>((n_groups + 3) / 4, (size_t)c->n_cu * 8));
+            if (path_small && c->sc.n_walk_words > 0) hipLaunchKernelGGL(k_classify<true>, cg, dim3(kBlock), 0, s, a, c->d_order, c->d_queue + 1, (uint32_t)n_groups);
+            else hipLaunchKernelGGL(k_classify<false>, cg, dim3(kBlock), 0, s, a, c->d_order, c->d_queue + 1, (uint32_t)n_groups);
+        }
+        // A launch ends when its slowest unit ends, and a unit through a glass sphere runs several milliseconds. So the bulk of
+        // a pass is handed out in units of `unit_blocks` blocks (one lane keeps a pixel for 64 samples: little bookkeeping), and
+        // its last `fine_blocks` blocks in single-block units by a SECOND launch on a second stream: its workgroups move into the
+        // slots the first launch's workgroups vacate as they run dry, so the machine stays full until only 16-sample units are
+        // left (measured on the 1/8 shard of the metric frame: see DESIGN.md section 6).
+        const size_t U = (size_t)tune.path_unit_blocks, F = (size_t)tune.path_fine_blocks;
         for (size_t b0 = 0; b0 < n_blocks; b0 += pass_blocks) {
             const size_t nb = std::min(pass_blocks, n_blocks - b0);
-            const size_t jb = std::min<size_t>((size_t)tune.path_job_blocks, nb);
-            const size_t n_ranges = (nb + jb - 1) / jb;
-            const size_t n_jobs = n_groups * n_ranges;
-            if (n_jobs > 0xfffffff0ull) return fail(c, RTW_ERR_UNSUPPORTED, "too many k_path jobs");
-            KArgs a = base;
-            a.stats = c->d_stats;
-            a.sample0 = (uint32_t)P->sample_offset;
-            a.queue = c->d_queue;
-            a.blocksum = c->blocksum;
-            a.n_jobs = (uint32_t)n_jobs; a.n_ranges = (uint32_t)n_ranges; a.blocks_per_job = (uint32_t)jb;
-            a.block0 = (uint32_t)b0; a.n_blocks_pass = (uint32_t)nb;
-            HIP_TRY_C(hipMemsetAsync(c->d_queue, 0, 64, s));
-            const int grid = (int)std::min<size_t>((size_t)c->n_cu * (size_t)wg_per_cu, (n_jobs + 3) / 4);
-            HIP_TRY_C(timed_launch(s, path_tree ? LK_PATH_TREE : LK_PATH, a, grid, path_lds));
-            launches++;
+            size_t nb_coarse = nb > 4 * F ? ((nb - F) / U) * U : 0;  // short passes are all fine units
+            HIP_TRY_C(hipMemsetAsync(c->d_queue, 0, 4, s));
+            HIP_TRY_C(hipMemsetAsync(c->d_queue + 4, 0, 4, s));
+            hipEvent_t ev_a = nullptr, ev_b = nullptr;  // (from the call's event pool, like the wavefront lanes' start event)
+            HIP_TRY_C(new_event(ev_a));
+            HIP_TRY_C(new_event(ev_b));
+            HIP_TRY_C(hipEventRecord(ev_a, s));
+            for (int part = 0; part < 2; part++) {
+                const size_t first = part == 0 ? 0 : nb_coarse, count = part == 0 ? nb_coarse : nb - nb_coarse;
+                if (count == 0) continue;
+                const size_t ub = part == 0 ? U : 1;
+                const size_t n_units = (count + ub - 1) / ub;                     // units per pixel in this launch
+                const size_t jb = std::min<size_t>((size_t)tune.path_job_blocks, n_units);  // units per pixel and job
+                const size_t n_ranges = (n_units + jb - 1) / jb;
+                const size_t n_jobs = n_groups * n_ranges;
+                if (n_jobs > 0xfffffff0ull) return fail(c, RTW_ERR_UNSUPPORTED, "too many k_path jobs");
+                KArgs a = base;
+                a.stats = c->d_stats;
+                a.sample0 = (uint32_t)P->sample_offset;
+                a.queue = c->d_queue + (part == 0 ? 0 : 4);
+                a.order = c->d_order;
+                a.order_counts = c->d_queue + 1;
+                a.blocksum = c->blocksum + first * npix;
+                a.n_jobs = (uint32_t)n_jobs; a.n_ranges = (uint32_t)n_ranges; a.blocks_per_job = (uint32_t)jb;
+                a.block0 = (uint32_t)(b0 + first); a.n_blocks_pass = (uint32_t)count; a.unit_blocks = (uint32_t)ub;
+                const int grid = (int)std::min<size_t>((size_t)c->n_cu * (size_t)wg_per_cu, (n_jobs + 3) / 4);
+                hipStream_t ls = part == 0 ? s : c->stream2;
+                if (part == 1) HIP_TRY_C(hipStreamWaitEvent(ls, ev_a, 0));
+                HIP_TRY_C(timed_launch(ls, path_tree ? LK_PATH_TREE : LK_PATH, a, grid, path_lds));
+                launches++;
+                if (part == 1) {
+                    HIP_TRY_C(hipEventRecord(ev_b, ls));
+                    HIP_TRY_C(hipStreamWaitEvent(s, ev_b, 0));
+                }
+            }
             hipLaunchKernelGGL(k_resolve_blocks, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->blocksum, c->accum, (uint32_t)npix, (uint32_t)nb);
         }
         hipLaunchKernelGGL(k_finish, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->accum, (const float4*)nullptr, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);

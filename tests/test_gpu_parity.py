@@ -199,8 +199,8 @@ def test_textured_scene_through_the_fused_path(gpu):
 
 def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
     """Pipeline (k_path with paths in registers vs the wavefront kernels), lanes, pool size, tail start, fused vs split
-    (with and without media), LDS budget, grid size, job size, block-sum passes: tuning knobs move work between kernels,
-    lanes and streams, never a bit of the image or a count."""
+    (with and without media), LDS budget, grid size, job and unit size, the fine-grained end-game launch, block-sum passes:
+    tuning knobs move work between kernels, lanes and streams, never a bit of the image or a count."""
     cases = [(abi.build_scene(0, 96, 64), 96, 64, 150, 30), (abi.build_scene(3, 64, 64), 64, 64, 10, 30),
              (oracle.random_scene(18, 80, 60, n_prims=70, volumes=True, motion=True, n_lights=2), 80, 60, 6, 30),
              (oracle.textured_cornell(64, 48, extra=30), 64, 48, 6, 20)]
@@ -210,7 +210,9 @@ def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
             {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "0"}, {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "30"}]
     knobs = [{}, {"RTW_PATH_TREE": "1"}, {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_PATH_JOB_BLOCKS": "1", "RTW_PATH_GRID_MULT": "1"},
              {"RTW_PATH_JOB_BLOCKS": "7", "RTW_BLOCKSUM_BYTES": "65536"}, {"RTW_PATH_GRID_MULT": "2", "RTW_KERNEL_TIMING": "0"},
-             {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_LDS_KB": "0"}, {"RTW_PATH_TREE": "1", "RTW_LDS_KB": "40"}]
+             {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_LDS_KB": "0"}, {"RTW_PATH_TREE": "1", "RTW_LDS_KB": "40"},
+             {"RTW_PATH_FINE_BLOCKS": "1", "RTW_PATH_UNIT_BLOCKS": "3"}, {"RTW_PATH_FINE_BLOCKS": "0", "RTW_PATH_UNIT_BLOCKS": "4"},
+             {"RTW_PATH_FINE_BLOCKS": "2", "RTW_PATH_UNIT_BLOCKS": "7", "RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0"}]
     knobs += [dict(k, RTW_PATH="0") for k in wave]
     names = sorted({k for kn in knobs for k in kn})
     for blob, w, h, spp, depth in cases:
