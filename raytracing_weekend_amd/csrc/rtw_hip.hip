@@ -637,8 +637,9 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         if (texs[ti].type == RTW_TEX_CHECKER) ti = texs[texs[ti].odd].type == RTW_TEX_NOISE ? texs[ti].odd : texs[ti].even;
         if (texs[ti].type == RTW_TEX_NOISE) sc.noise_lds_data = (int32_t)texs[ti].data;
     }
-    // selects the kernel instantiations that contain the cold features: textures, media, (k_path) moving spheres in the brute lists
-    sc.has_tex = (has_tex || n_vol > 0 || n_generic > 0) ? 1 : 0;
+    // selects the kernel instantiations that contain the cold features: textures, media, (k_path) moving spheres in the brute lists,
+    // camera kinds other than the reference's lens-free perspective camera
+    sc.has_tex = (has_tex || n_vol > 0 || n_generic > 0 || h.camera_type != RTW_CAM_PERSPECTIVE || h.camera.lens_radius != 0.0f) ? 1 : 0;
     sc.n_groups = (int)groups.size();
     sc.n_generic = n_generic;
     sc.n_prims = (int)h.n_prims;

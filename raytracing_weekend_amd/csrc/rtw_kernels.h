@@ -32,6 +32,12 @@ using namespace rtwdev;
 #ifndef RTW_MIN_WAVES
 #define RTW_MIN_WAVES 1
 #endif
+// ISA comment markers inside device functions (scripts/isa_phases.sh, -DRTW_MARKERS only)
+#ifdef RTW_MARKERS
+#define RTW_MARK2(name) asm volatile("; MARK " name)
+#else
+#define RTW_MARK2(name)
+#endif
 constexpr int kBlock = 256;                       // 4 wave64 per workgroup
 constexpr uint32_t kMaxRegions = 2048;            // region counters scanned in LDS by every workgroup (>= the compacting grid)
 constexpr uint32_t kZombie = 0x80000000u;
@@ -71,6 +77,16 @@ struct Path {
     float ltmax;
     v3 T, L, c;
     uint32_t w0, a, b;
+};
+
+// k_path's per-workgroup LDS copy of the constants its loop reads every iteration (camera frame of the perspective camera,
+// the pdf rectangle, light 0): as kernel arguments they would sit in ~35 SGPRs for the whole launch, which the register
+// allocator pays for with spills into VGPR lanes (v_writelane / v_readlane in the loop) and a scalar load of the light record
+// per vertex; from LDS they are a few broadcast reads where they are used
+struct PathConsts {
+    float cam_o[4], cam_ll[4], cam_h[4], cam_v[4];
+    float rect[5]; int32_t gen; float pad[2];
+    float lnrm[3], larea, lemi[3], pad2;
 };
 
 RTW_DEV void load_trace_part(const PathBuf& B, size_t s, Path& p) {
@@ -179,7 +195,8 @@ struct Nee {
 // TEX: the instantiation for scenes with non-constant textures or media (the cold features)
 template <int KIND, bool TEX>
 RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 dir, const float gather_time, const float t, const int prim,
-                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee, const uint32_t* noise_lds, uint32_t& nee_prev, const u32x4* hr_lds = nullptr) {
+                    v3& so, v3& sd, v3& att, v3& radiance, Nee& nee, const uint32_t* noise_lds, uint32_t& nee_prev, const u32x4* hr_lds = nullptr,
+                    const PathConsts* pc = nullptr) {
     // nee_prev (corrected estimator only): in - a light sample was taken at the previous vertex; out - one was taken here
     const int est = TEX ? sc.estimator : 0;
     const uint32_t had_nee = nee_prev;
@@ -198,6 +215,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         }
         return EV_MISS;
     }
+    RTW_MARK2("sa_hitrec");
     g.align_block();
     const HitRec hr = load_hitrec(sc, prim, hr_lds);
     if (hr.mat_type != RTW_MAT_DIFFUSE_LIGHT && hr.mat_type != RTW_MAT_NORMAL) g.warm();
@@ -209,6 +227,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     if (TEX && hr.tex_dyn >= 0) tex = texture_eval(sc, hr, prim, origin, dir, t, 0.0f, hp, hn, noise_lds);  // checker / noise / image
     int ev;
     bool specular = false;
+    RTW_MARK2("sa_lambert");
     if (mtype == RTW_MAT_LAMBERTIAN) {
         // lambertianMaterial.cu:41-71, onb.cuh:20-32, sampling.cuh:49-60 (Q1)
         v3 u, v, w;
@@ -246,12 +265,14 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         ev = EV_HIT;
         if (cosine <= 0.0f || pdf <= 0.0f) ev = EV_CANCEL;
         else att = tex;
+    RTW_MARK2("sa_light");
     } else if (mtype == RTW_MAT_DIFFUSE_LIGHT) {
         // diffuseLight.cu:48-69
         if (dot3(hn, dir) < 0.0f) radiance = tex;
         // corrected: the light sample of the previous vertex already accounted for this emitter
         if (est == RTW_EST_CORRECTED && had_nee != 0u && hr.listed != 0) radiance = V(0.f, 0.f, 0.f);
         ev = EV_CANCEL;
+    RTW_MARK2("sa_metal");
     } else if (mtype == RTW_MAT_METAL) {
         // metalMaterial.cu:32-64 (Q5)
         specular = true;
@@ -261,6 +282,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         so = hp; sd = sdir;
         att = tex;
         ev = (dot3(sdir, hn) <= 0.0f) ? EV_CANCEL : EV_HIT;
+    RTW_MARK2("sa_diel");
     } else if (mtype == RTW_MAT_DIELECTRIC) {
         // dielectricMaterial.cu:37-114
         specular = true;
@@ -294,6 +316,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         so = hp; sd = sdir;
         att = V(1.f, 1.f, 1.f);
         ev = EV_HIT;
+    RTW_MARK2("sa_iso");
     } else if (mtype == RTW_MAT_ISOTROPIC) {
         // isotropicMaterial.cu:30-51 (Q14)
         specular = true;
@@ -308,6 +331,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         ev = EV_FINISH;
     }
 
+    RTW_MARK2("sa_nee");
     // next-event estimation, closehit.cu:70-94: sample the light; the visibility probe comes later
     const int nl = sc.n_lights;
     if (est == RTW_EST_CORRECTED && ev == EV_HIT && !specular && nl > 0) {
@@ -356,14 +380,24 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
             lnrm = V(lt->normal[0], lt->normal[1], lt->normal[2]);
             lemi = V(lt->emission[0], lt->emission[1], lt->emission[2]);
             larea = lt->area;
+        } else if (pc != nullptr) {
+            lnrm = ld3(pc->lnrm); lemi = ld3(pc->lemi); larea = pc->larea;
         } else {
             const RTW_CONST rtw_light* lt = as_const(sc.lights);
             lnrm = V(lt->normal[0], lt->normal[1], lt->normal[2]);
             lemi = V(lt->emission[0], lt->emission[1], lt->emission[2]);
             larea = lt->area;
         }
-        int gen = sc.pdf.gen;  // mixturePdf.cu:25-38: always child p1 (Q4)
-        if (gen == RTW_PDF_MIXTURE || gen == RTW_PDF_MIXTURE_BIAS) gen = sc.pdf.p1_gen;
+        int gen;  // mixturePdf.cu:25-38: always child p1 (Q4)
+        float rc0, rc1, rc2, rc3, rc4;
+        if (pc != nullptr) {
+            gen = __builtin_amdgcn_readfirstlane(pc->gen);
+            rc0 = pc->rect[0]; rc1 = pc->rect[1]; rc2 = pc->rect[2]; rc3 = pc->rect[3]; rc4 = pc->rect[4];
+        } else {
+            gen = sc.pdf.gen;
+            if (gen == RTW_PDF_MIXTURE || gen == RTW_PDF_MIXTURE_BIAS) gen = sc.pdf.p1_gen;
+            rc0 = sc.pdf.rect[0]; rc1 = sc.pdf.rect[1]; rc2 = sc.pdf.rect[2]; rc3 = sc.pdf.rect[3]; rc4 = sc.pdf.rect[4];
+        }
         float lpdf = 0.0f, ldist = 0.0f;
         v3 ldir = V(0.f, 0.f, 0.f), lem = V(0.f, 0.f, 0.f);
         if (gen == RTW_PDF_RECT_X || gen == RTW_PDF_RECT_Y || gen == RTW_PDF_RECT_Z) {
@@ -377,9 +411,9 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
                 ra = g.next1();
                 rb = g.next1();
             }
-            float pa = fma_(ra, sc.pdf.rect[1] - sc.pdf.rect[0], sc.pdf.rect[0]);
-            float pb = fma_(rb, sc.pdf.rect[3] - sc.pdf.rect[2], sc.pdf.rect[2]);
-            float k = sc.pdf.rect[4];
+            float pa = fma_(ra, rc1 - rc0, rc0);
+            float pb = fma_(rb, rc3 - rc2, rc2);
+            float k = rc4;
             v3 rp = (gen == RTW_PDF_RECT_X) ? V(k, pa, pb) : (gen == RTW_PDF_RECT_Y) ? V(pa, k, pb) : V(pa, pb, k);
             ldir = vsub(rp, so);
             ldist = length3(ldir);
@@ -540,8 +574,9 @@ RTW_DEV const uint32_t* stage_noise(const DScene& sc, uint32_t* s_noise) {
 
 // __raygen__Program (raygen.cu:123-147) + perspectiveCamera (camera.cu:11-19) + color() (raygen.cu:89-95): the camera
 // path of sample `sample` of image pixel (x, y); shared by k_first and k_path so that both draw the same numbers.
-template <int KIND>
-RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const uint32_t sample, const uint32_t path_id, Path& p, Rng<KIND>& g) {
+template <int KIND, bool LDS_CAM = false>
+RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const uint32_t sample, const uint32_t path_id, Path& p, Rng<KIND>& g,
+                    const PathConsts* pc = nullptr) {
     const uint32_t pixel = A.width * y + x;
     float r0, r1, r2, r3, r4;
     if (KIND == RTW_RNG_TEA_LCG) {
@@ -562,6 +597,18 @@ RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const ui
     const rtw_camera& cam = A.sc.cam;
     const float s = ((float)x + r0) / (float)A.width;
     const float t = ((float)y + r1) / (float)A.height;
+    if (LDS_CAM) {  // k_path, perspective camera without a lens: the frame comes from LDS (same values, same operations)
+        p.o = ld3(pc->cam_o);
+        p.d = vfma(ld3(pc->cam_h), s, ld3(pc->cam_ll));
+        p.d = vfma(ld3(pc->cam_v), t, p.d);
+        p.d = vsub(p.d, p.o);
+        p.gk = (uint32_t)(r4 * 16777216.0f);
+        p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(0u) : 0.0f;
+        p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;
+        p.T = V(1.f, 1.f, 1.f); p.L = V(0.f, 0.f, 0.f); p.c = V(0.f, 0.f, 0.f);
+        p.a = g.a; p.b = g.b;
+        return;
+    }
     p.o = ld3(cam.origin);
     if (cam.lens_radius != 0.0f) {  // sampling.cuh:15-22; the two draws are consumed either way
         float sn, cs;
@@ -1114,6 +1161,24 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
         const u32x4* src = (const u32x4*)A.sc.hitrec;
         for (uint32_t i = tid; i < (uint32_t)A.sc.n_prims * 6u; i += kBlock) s_hitrec[i] = src[i];
     }
+    __shared__ PathConsts s_pc;
+    if (tid == 0) {
+        for (int q = 0; q < 3; q++) {
+            s_pc.cam_o[q] = A.sc.cam.origin[q]; s_pc.cam_ll[q] = A.sc.cam.lower_left[q];
+            s_pc.cam_h[q] = A.sc.cam.horizontal[q]; s_pc.cam_v[q] = A.sc.cam.vertical[q];
+        }
+        for (int q = 0; q < 5; q++) s_pc.rect[q] = A.sc.pdf.rect[q];
+        int gen = A.sc.pdf.gen;
+        if (gen == RTW_PDF_MIXTURE || gen == RTW_PDF_MIXTURE_BIAS) gen = A.sc.pdf.p1_gen;
+        s_pc.gen = gen;
+        if (A.sc.n_lights > 0) {
+            for (int q = 0; q < 3; q++) { s_pc.lnrm[q] = A.sc.lights[0].normal[q]; s_pc.lemi[q] = A.sc.lights[0].emission[q]; }
+            s_pc.larea = A.sc.lights[0].area;
+        }
+    }
+    // the LDS camera serves the perspective camera without a lens (the reference's only camera); other kinds read the arguments
+    // (the host sends other camera kinds and thin lenses through the cold instantiation, which reads the arguments)
+    const PathConsts* pc_cam = TEX ? nullptr : &s_pc;
     __shared__ u32x4 s_walk[TEX ? 1 : kWalkMaxWords];
     if (!TEX) for (uint32_t i = tid; i < (uint32_t)A.sc.n_walk_words; i += kBlock) s_walk[i] = A.sc.walk[i];
     __syncthreads();
@@ -1179,7 +1244,7 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
         Rng<KIND> g;
         if (busy && !alive) {  // regeneration: the next camera path of this lane's unit
             Path p;
-            raygen<KIND>(A, px, py, A.sample0 + s_cur, 0u, p, g);
+            raygen<KIND, !TEX>(A, px, py, A.sample0 + s_cur, 0u, p, g, pc_cam);
             o = p.o; d = p.d; T = p.T; L = p.L; rng_a = p.a;
             if (TEX) { ray_time = p.ray_time; gk = p.gk; rng_b = p.b; nee_prev = 0; }
             depth = 0; alive = true;
@@ -1205,7 +1270,7 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
         if (busy) {
             v3 so, sd, att, radiance;
             Nee nee;
-            const int ev = shade_a<KIND, TEX>(A.sc, g, o, d, gt, th, prim, so, sd, att, radiance, nee, noise_lds, nee_prev, s_hitrec);
+            const int ev = shade_a<KIND, TEX>(A.sc, g, o, d, gt, th, prim, so, sd, att, radiance, nee, noise_lds, nee_prev, s_hitrec, &s_pc);
             n_seg++;
             RTW_MARK("walk_s");
             if (nee.has) {  // traceOcclusion, closehit.cu:16-42
