@@ -215,7 +215,7 @@ def main():
                        "partition": f"{world} interleaved row shards (rank g: rows g, g+{world}, ...; {max_rows} rows each), one RCCL gather per step" if world > 1 else "single tile",
                        "segments_per_sample": round(segments / samples, 4),
                        "shadow_rays_per_sample": round(shadow / samples, 4),
-                       "pipeline": "k_path: paths in registers, lanes own (pixel, 64-sample block) units and regenerate" if in_regs
+                       "pipeline": "k_path: paths in registers, lanes own (pixel, 4 x 16-sample block) units and regenerate; one bulk launch + a concurrent fine-grained end-game launch per pass" if in_regs
                                    else "wavefront: k_first / k_trace / k_shade / k_bounce over SoA path state in HBM"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
@@ -224,7 +224,7 @@ def main():
                          "kernel": names[dom], "launches": int(k_n[dom]),
                          "avg_launch_us": round(k_s[dom] / k_n[dom] * 1e6, 3) if k_n[dom] else None,
                          "algorithmic_bytes_per_launch": round(128.0 * dom_units / k_n[dom], 1) if k_n[dom] else None,
-                         "note": ("achieved = 128 B x segments / kernel time (SURVEY 8d). k_path never writes path state: the state the "
+                         "note": ("achieved = 128 B x segments / kernel time (SURVEY 8d; the pass's two overlapping k_path launches are timed as one, from before the first to after both). k_path never writes path state: the state the "
                                   "algorithmic figure counts stays in registers, only 16 B per pixel and 64 samples reach HBM (traffic), so "
                                   "the kernel is bound by VALU issue, not by HBM: see roofline.valu") if in_regs else
                                  "two batches are in flight on two streams (lanes), so a kernel's own launch duration includes sharing "

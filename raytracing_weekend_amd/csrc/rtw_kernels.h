@@ -218,7 +218,9 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     RTW_MARK2("sa_hitrec");
     g.align_block();
     const HitRec hr = load_hitrec(sc, prim, hr_lds);
-    if (hr.mat_type != RTW_MAT_DIFFUSE_LIGHT && hr.mat_type != RTW_MAT_NORMAL) g.warm();
+    // the segment's first Philox block, generated while the whole wave is on one code path and - not depending on the hit
+    // record - while its LDS reads are in flight (a light or normal-material vertex draws nothing: its block is simply unused)
+    g.warm();
     v3 hp, hn;
     hit_attributes(sc, hr, prim, origin, dir, t, gather_time, hp, hn);
     const int mtype = hr.mat_type;

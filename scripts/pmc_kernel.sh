@@ -4,6 +4,8 @@
 # (never combined with tracing: gpurun refuses that). Writes gpurun_out/pmc_<tag>/summary.json.
 set -e
 export TMPDIR=/tmp
+# one k_path dispatch per render (no concurrent end-game launch), so that a dispatch's counters cover all the segments counted
+export RTW_PATH_FINE_BLOCKS=0
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd $R
 TAG=$1; KERN=$2; shift 2
