@@ -863,7 +863,7 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
                 a.order = c->d_order;
                 a.order_counts = c->d_queue + 1;
                 a.blocksum = c->blocksum + first * npix;
-                a.n_jobs = (uint32_t)n_jobs; a.n_ranges = (uint32_t)n_ranges; a.blocks_per_job = (uint32_t)jb;
+                a.n_jobs = (uint32_t)n_jobs; a.n_ranges = (uint32_t)n_ranges; a.units_per_job = (uint32_t)jb;
                 a.block0 = (uint32_t)(b0 + first); a.n_blocks_pass = (uint32_t)count; a.unit_blocks = (uint32_t)ub;
                 const int grid = (int)std::min<size_t>((size_t)c->n_cu * (size_t)wg_per_cu, (n_jobs + 3) / 4);
                 hipStream_t ls = part == 0 ? s : c->stream2;

@@ -32,12 +32,12 @@ using namespace rtwdev;
 #ifndef RTW_MIN_WAVES
 #define RTW_MIN_WAVES 1
 #endif
-// ISA comment markers inside device functions (scripts/isa_phases.sh, -DRTW_MARKERS only)
-#ifdef RTW_MARKERS
+// Phase fences. An `asm volatile` statement (here: nothing but a comment in the ISA) is a point the instruction scheduler does
+// not move work across. k_path's loop body is one long straight-line region to it, and without fences it hoists loads and
+// address arithmetic of later phases over earlier ones until the 96-register budget of 5 waves per SIMD overflows (88 bytes
+// of scratch per lane in the hot loop); with a fence at every phase boundary the same code allocates without a spill and
+// the metric workload runs 3.5 % faster. scripts/isa_phases.sh counts instructions between the comments.
 #define RTW_MARK2(name) asm volatile("; MARK " name)
-#else
-#define RTW_MARK2(name)
-#endif
 constexpr int kBlock = 256;                       // 4 wave64 per workgroup
 constexpr uint32_t kMaxRegions = 2048;            // region counters scanned in LDS by every workgroup (>= the compacting grid)
 constexpr uint32_t kZombie = 0x80000000u;
@@ -63,7 +63,7 @@ struct KArgs {
     // k_path (register-resident paths with in-wave regeneration)
     uint32_t* queue;            // [0]: next job of the launch (one returning atomic per job and wave)
     float4* blocksum;           // [block - block0][shard-local pixel]: sum of the block's samples in sample order
-    uint32_t n_jobs, n_ranges, blocks_per_job, block0, n_blocks_pass, spp;
+    uint32_t n_jobs, n_ranges, units_per_job, block0, n_blocks_pass, spp;
     uint32_t unit_blocks;       // consecutive sample blocks a lane takes as one unit (one 16-byte sum is stored per block)
     const uint32_t* order;      // job order of the 64-pixel groups: three lists, longest units first (k_classify)
     const uint32_t* order_counts;  // lengths of the lists of classes 2, 1, 0
@@ -1127,26 +1127,25 @@ __global__ void __launch_bounds__(kBlock) k_classify(const KArgs A, uint32_t* __
 }
 
 // ------------------------------------------------------------------ k_path
-// Small scenes (scalar-cache candidate lists): the whole path lives in registers. A lane owns one UNIT at a time - one
-// pixel, one block of kSumBlock consecutive samples - and walks the unit's paths one segment per loop iteration: camera
+// Small scenes (the candidate lists): the whole path lives in registers. A lane owns one UNIT at a time - one pixel,
+// unit_blocks consecutive blocks of kSumBlock samples - and walks the unit's paths one segment per loop iteration: camera
 // ray when it has none (regeneration), closest hit, closest-hit / miss program, the light sample's shadow probe, roulette.
-// A finished sample is added to the unit's sum in sample order; a finished unit stores its sum and the lane takes the
-// next unit of its wave's stream (ballot + mbcnt ranks, no atomics). A wave's stream is a queue of jobs (64 neighbouring
-// pixels x blocks_per_job blocks), one returning atomic per job, so lanes never wait for each other: every iteration
-// runs with all 64 lanes on live paths until the launch runs dry. Nothing but the 16-byte unit sums reaches HBM.
-// The image does not depend on which lane ran which unit: a unit's sum is a function of (pixel, block) alone, and the
-// per-pixel sums are taken block by block in order (k_resolve_blocks) - the summation order of the arithmetic spec.
+// A finished sample is added to the current block's sum in sample order; a finished block stores its 16-byte sum; after the
+// unit's last block the lane takes the next unit of its wave's stream (ballot + mbcnt ranks, no atomics). A wave's stream
+// is a queue of jobs (64 neighbouring pixels x units_per_job units), one returning atomic per job, so lanes never wait for
+// each other: every iteration runs with all 64 lanes on live paths until the launch runs dry. Nothing but the block sums
+// reaches HBM. The image does not depend on which lane ran which unit: a block's sum is a function of (pixel, block) alone,
+// and the per-pixel sums are taken block by block in order (k_resolve_blocks) - the summation order of the arithmetic spec.
+// The host runs a pass as two overlapping launches (rtw_hip.hip): the bulk in 4-block units, the last blocks one by one.
 constexpr uint32_t kSumBlock = RTW_SUM_BLOCK;
 constexpr int kPathMaxPrims = 64;  // k_path walks the brute lists only: scenes of at most this many primitives
-// diagnostics (never in the shipped build): RTW_MARKERS leaves "; MARK <phase>" comments in the ISA for per-phase
-// instruction counts; RTW_PHASE_TIMERS accumulates s_memtime deltas per phase and wave (printed by the host)
+// RTW_MARK: a phase fence (see RTW_MARK2 above); the diagnostic build -DRTW_PHASE_TIMERS (never shipped) also accumulates
+// s_memtime deltas per phase and wave there (printed by the host)
 #if defined(RTW_PHASE_TIMERS)
 #define RTW_MARK(name) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); ph_cyc[ph_cur] += now_ - ph_t0; ph_t0 = now_; ph_cur = rtw_phase_id(name); }
 RTW_DEV constexpr int rtw_phase_id(const char* n) { return n[0] == 'r' && n[2] == 'f' ? 0 : n[0] == 'r' ? 1 : n[0] == 'w' && n[5] == 'r' ? 2 : n[0] == 's' && n[6] == 'a' ? 3 : n[0] == 'w' ? 4 : 5; }
-#elif defined(RTW_MARKERS)
-#define RTW_MARK(name) asm volatile("; MARK " name)
 #else
-#define RTW_MARK(name)
+#define RTW_MARK(name) asm volatile("; MARK " name)
 #endif
 // waves per SIMD the register allocation aims at: 5 (<= 96 VGPRs) for the instantiation without the cold features - measured
 // +9 % over 4 on the metric workload, 6 adds nothing; the cold instantiation needs the registers more than the occupancy
@@ -1215,8 +1214,8 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
                 if (q >= A.n_jobs) { exhausted = true; break; }
                 const uint32_t gi = q / A.n_ranges;
                 job_g = order_lookup(A, gi);
-                job_b = (q - gi * A.n_ranges) * A.blocks_per_job;
-                u_next = 0; u_end = 64u * A.blocks_per_job;
+                job_b = (q - gi * A.n_ranges) * A.units_per_job;
+                u_next = 0; u_end = 64u * A.units_per_job;
                 continue;
             }
             const uint32_t avail = u_end - u_next;
@@ -1390,8 +1389,8 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
                 if (q >= A.n_jobs) { exhausted = true; break; }
                 const uint32_t gi = q / A.n_ranges;
                 job_g = order_lookup(A, gi);
-                job_b = (q - gi * A.n_ranges) * A.blocks_per_job;
-                u_next = 0; u_end = 64u * A.blocks_per_job;
+                job_b = (q - gi * A.n_ranges) * A.units_per_job;
+                u_next = 0; u_end = 64u * A.units_per_job;
                 continue;
             }
             const uint32_t avail = u_end - u_next;
