@@ -1,4 +1,5 @@
-// rtw_bvh.h — host BVH2 builder over world-space primitive bounds.
+// rtw_bvh.h — host tree builder over world-space primitive bounds: a binned-SAH BVH2, collapsed into the 4-wide tree with
+// 8-bit child boxes that the GPU walks (Q4Node), and the leaf records in tree order (LeafRec).
 // Replaces the closed OptiX accel builds the reference calls per primitive and per scene
 // (geometry/ioSphere.h:45-106, ioAARect.h:41-154, ioMovingSphere.h:46-72,90-218,
 //  ioGeometryGroup.h:160-225): one AABB per primitive in object space, carried to world space by
@@ -101,22 +102,43 @@ inline Box world_bounds(const rtw_prim& p, const rtw_xform& xf) {
     return wb;
 }
 
-// What the GPU walks: one 64-byte record per INNER node holding the bounds of both children, so a traversal
-// step is one burst of four 16-byte loads and the child that is entered next needs no load of its own box.
-// A child reference is idx | count << 30: count > 0 (1 or 2) is a leaf whose idx is its first entry in
-// prim_order; count == 0 is an inner node and idx its wide-node index.
-struct WideNode {
-    float lmn[3]; uint32_t lref;
-    float lmx[3]; uint32_t pad0;
-    float rmn[3]; uint32_t rref;
-    float rmx[3]; uint32_t pad1;
+// What the GPU walks: a 4-wide tree. One 64-byte record per inner node holds the boxes of up to four children, quantised
+// to 8 bits per plane on a grid of the node's own (origin p = the node's box minimum, one power-of-two step per axis, stored as a float), so a
+// traversal step is one burst of four 16-byte loads for four box tests, the tree of a few thousand primitives fits the
+// LDS, and a walk has half the dependent steps of the binary tree. Quantisation only ever grows a box (floor / ceil,
+// checked in double), and boxes only cull: exact hits are decided by the primitive tests, so the image does not depend
+// on the tree. A child reference is idx << 2 | count: count 1 or 2 = a leaf whose idx is its first LeafRec, count 0 = an
+// inner node; kQ4Empty marks an unused slot.
+constexpr uint32_t kQ4Empty = 0xffffffffu;
+struct Q4Node {
+    float p[3];
+    float sx;           // grid steps: powers of two
+    uint32_t lo[3];     // byte c of lo[a]: child c's lower plane on axis a, in grid steps from p[a]
+    uint32_t hi[3];     // upper planes
+    float sy, sz;
+    uint32_t ref[4];
 };
+static_assert(sizeof(Q4Node) == 64, "Q4Node layout");
+
+// A leaf entry in tree order: what the intersection programs of spheres and rectangles read (p[0..4] of rtw_prim), so a
+// leaf visit is one 32-byte load instead of index -> primitive record; other kinds (moving spheres) keep kind = their
+// type and are fetched from the primitive table.
+struct LeafRec {
+    float p[5];
+    int32_t prim;
+    uint32_t type_xform;  // rtw_prim_type | xform << 8
+    uint32_t pad;
+};
+static_assert(sizeof(LeafRec) == 32, "LeafRec layout");
 
 struct Bvh {
     std::vector<Node> nodes;
-    std::vector<WideNode> wide;       // inner nodes only; wide[0] is the root
+    std::vector<Q4Node> q4;           // the 4-wide tree, breadth-first; q4[0] is the root
+    std::vector<LeafRec> leaves;      // leaf entries in tree order
     std::vector<int32_t> prim_order;  // leaf entries -> primitive index
-    int max_depth = 0;
+    int max_depth = 0;                // of the BVH2
+    int stack_need = 0;               // most entries a walk of the 4-wide tree can have on its stack (+ 1 of slack)
+    int max_exp = -100;               // largest grid step of a node is 2^max_exp
 };
 
 namespace detail {
@@ -184,6 +206,84 @@ inline void build(std::vector<Item>& items, int lo, int hi, int node_idx, int de
     build(items, lo, mid, left, depth + 1, out);
     build(items, mid, hi, left + 1, depth + 1, out);
 }
+
+inline float node_area(const Node& n) {
+    float dx = n.mx[0] - n.mn[0], dy = n.mx[1] - n.mn[1], dz = n.mx[2] - n.mn[2];
+    return 2.f * (dx * dy + dy * dz + dz * dx);
+}
+
+// BVH2 -> 4-wide: a node adopts its grandchildren, the child of the largest area first, until it has four children or
+// only leaves. Nodes are numbered breadth-first so that a prefix of the array is the top of the tree.
+inline void collapse(Bvh& out) {
+    const std::vector<Node>& nodes = out.nodes;
+    std::vector<std::vector<uint32_t>> kids;  // per 4-wide node: BVH2 node indices of its children
+    std::vector<uint32_t> src;                // per 4-wide node: the BVH2 node it stands for
+    std::vector<int32_t> q4_of(nodes.size(), -1);
+    std::vector<uint32_t> queue;
+    if (nodes[0].count == 0) queue.push_back(0u);
+    for (size_t q = 0; q < queue.size(); q++) {
+        const uint32_t ni = queue[q];
+        q4_of[ni] = (int32_t)q;
+        std::vector<uint32_t> ch{nodes[ni].left_first, nodes[ni].left_first + 1};
+        while (ch.size() < 4) {
+            int best = -1; float ba = -1.f;
+            for (size_t k = 0; k < ch.size(); k++)
+                if (nodes[ch[k]].count == 0 && node_area(nodes[ch[k]]) > ba) { ba = node_area(nodes[ch[k]]); best = (int)k; }
+            if (best < 0) break;
+            const uint32_t c = ch[(size_t)best];
+            ch[(size_t)best] = nodes[c].left_first;
+            ch.push_back(nodes[c].left_first + 1);
+        }
+        for (uint32_t c : ch) if (nodes[c].count == 0) queue.push_back(c);
+        kids.push_back(ch); src.push_back(ni);
+    }
+    if (queue.empty()) {  // the root is a leaf (one or two surfaces): one 4-wide node with that single child
+        kids.push_back(std::vector<uint32_t>{0u}); src.push_back(0u);
+    }
+    out.q4.assign(kids.size(), Q4Node{});
+    std::vector<int> need(kids.size(), 0);
+    for (size_t qi = kids.size(); qi-- > 0;) {
+        const Node& nb = nodes[src[qi]];
+        Q4Node& w = out.q4[qi];
+        double step[3];
+        for (int a = 0; a < 3; a++) {
+            w.p[a] = nb.mn[a];
+            const double ext = (double)nb.mx[a] - (double)nb.mn[a];
+            int e = -100;  // 2^e * 255 >= extent
+            if (ext > 0.0) { e = (int)std::ceil(std::log2(ext / 255.0)); if (e < -100) e = -100; }
+            for (;;) {  // the children's planes must fit 0..255 steps, rounding outwards
+                bool ok = true;
+                const double s2 = std::ldexp(1.0, e);
+                for (uint32_t c : kids[qi]) if (std::ceil(((double)nodes[c].mx[a] - (double)w.p[a]) / s2) > 255.0) ok = false;
+                if (ok) break;
+                e++;
+            }
+            step[a] = std::ldexp(1.0, e);
+            out.max_exp = std::max(out.max_exp, e);
+        }
+        w.sx = (float)step[0]; w.sy = (float)step[1]; w.sz = (float)step[2];
+        for (int a = 0; a < 3; a++) { w.lo[a] = 0xffffffffu; w.hi[a] = 0u; }  // unused slots: an inverted box
+        int nd = 0;
+        for (size_t k = 0; k < 4; k++) {
+            if (k >= kids[qi].size()) { w.ref[k] = kQ4Empty; continue; }
+            const Node& ch = nodes[kids[qi][k]];
+            for (int a = 0; a < 3; a++) {
+                double ql = std::floor(((double)ch.mn[a] - (double)w.p[a]) / step[a]);
+                double qh = std::ceil(((double)ch.mx[a] - (double)w.p[a]) / step[a]);
+                if (ql < 0.0) ql = 0.0;
+                if (qh > 255.0) qh = 255.0;
+                while (ql > 0.0 && (double)w.p[a] + ql * step[a] > (double)ch.mn[a]) ql -= 1.0;
+                while (qh < 255.0 && (double)w.p[a] + qh * step[a] < (double)ch.mx[a]) qh += 1.0;
+                w.lo[a] = (w.lo[a] & ~(0xffu << (8 * k))) | ((uint32_t)ql << (8 * k));
+                w.hi[a] = (w.hi[a] & ~(0xffu << (8 * k))) | ((uint32_t)qh << (8 * k));
+            }
+            if (ch.count) w.ref[k] = (ch.left_first << 2) | ch.count;
+            else { w.ref[k] = (uint32_t)q4_of[kids[qi][k]] << 2; nd = std::max(nd, need[(size_t)q4_of[kids[qi][k]]]); }
+        }
+        need[qi] = (int)kids[qi].size() - 1 + nd;
+    }
+    out.stack_need = need[0] + 1;
+}
 }  // namespace detail
 
 inline Bvh build_bvh(const rtw_prim* prims, uint32_t n_prims, const rtw_xform* xforms) {
@@ -206,42 +306,15 @@ inline Bvh build_bvh(const rtw_prim* prims, uint32_t n_prims, const rtw_xform* x
     detail::build(items, 0, static_cast<int>(items.size()), 0, 1, out);
     out.prim_order.resize(items.size());
     for (size_t i = 0; i < items.size(); i++) out.prim_order[i] = items[i].prim;
-    // inner nodes -> wide records, numbered breadth-first so that a prefix of the array is the top of the tree
-    std::vector<int32_t> wid(out.nodes.size(), -1);
-    int32_t nw = 0;
-    if (out.nodes[0].count == 0) {
-        std::vector<uint32_t> queue{0u};
-        for (size_t q = 0; q < queue.size(); q++) {
-            const Node& nd = out.nodes[queue[q]];
-            wid[queue[q]] = nw++;
-            for (uint32_t c = 0; c < 2; c++)
-                if (out.nodes[nd.left_first + c].count == 0) queue.push_back(nd.left_first + c);
-        }
+    for (size_t i = 0; i < items.size(); i++) {
+        const rtw_prim& pr = prims[items[i].prim];
+        LeafRec lr{};
+        for (int k = 0; k < 5; k++) lr.p[k] = pr.p[k];
+        lr.prim = items[i].prim;
+        lr.type_xform = (uint32_t)pr.type | ((uint32_t)pr.xform << 8);
+        out.leaves.push_back(lr);
     }
-    if (nw == 0) {
-        // The root is a leaf (one or two surfaces: a tree scene made of volumes, or RTW_BRUTE_MAX=0 on a tiny scene). The
-        // device walk always starts at inner record 0, so the leaf becomes the left child of one inner record whose right
-        // child is a box no ray reaches (a point at 3e38: its slab interval never meets [tmin, best_t]).
-        WideNode w{};
-        const Node& rt = out.nodes[0];
-        for (int a = 0; a < 3; a++) { w.lmn[a] = rt.mn[a]; w.lmx[a] = rt.mx[a]; w.rmn[a] = 3.0e38f; w.rmx[a] = 3.0e38f; }
-        w.lref = rt.left_first | (rt.count << 30);
-        w.rref = w.lref;
-        out.wide.push_back(w);
-        return out;
-    }
-    out.wide.resize((size_t)nw);
-    for (size_t i = 0; i < out.nodes.size(); i++) {
-        const Node& nd = out.nodes[i];
-        if (nd.count != 0) continue;
-        WideNode& w = out.wide[(size_t)wid[i]];
-        const Node& L = out.nodes[nd.left_first];
-        const Node& R = out.nodes[nd.left_first + 1];
-        for (int a = 0; a < 3; a++) { w.lmn[a] = L.mn[a]; w.lmx[a] = L.mx[a]; w.rmn[a] = R.mn[a]; w.rmx[a] = R.mx[a]; }
-        w.lref = (L.count ? L.left_first : (uint32_t)wid[nd.left_first]) | (L.count << 30);
-        w.rref = (R.count ? R.left_first : (uint32_t)wid[nd.left_first + 1]) | (R.count << 30);
-        w.pad0 = w.pad1 = 0;
-    }
+    detail::collapse(out);
     return out;
 }
 

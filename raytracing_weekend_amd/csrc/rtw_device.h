@@ -286,14 +286,8 @@ struct Rng<RTW_RNG_PHILOX> {
 };
 
 // ------------------------------------------------------------------ device scene
-// inner node of the BVH2 with the bounds of both children (rtw_bvh.h WideNode); ref = idx | leaf count << 30
-struct BvhNode {
-    float lmn[3]; uint32_t lref;
-    float lmx[3]; uint32_t pad0;
-    float rmn[3]; uint32_t rref;
-    float rmx[3]; uint32_t pad1;
-};
-
+// The tree: 64-byte nodes of the 4-wide tree with quantised child boxes, 32-byte leaf records in tree order (rtw_bvh.h
+// Q4Node, LeafRec). A reference is idx << 2 | count (count 0 = inner node, 1-2 = leaf of that many records).
 // Per-primitive hit record baked at upload (96 B, fetched with a burst of 16-byte loads once
 // the closest hit is known): material + its constant texture colour (texture/constantTexture.cu:5-10,
 // nullTexture.cu:7-12) and everything the shading normal needs, so that no primitive / transform
@@ -338,8 +332,8 @@ struct DScene {
     const rtw_xform* __restrict__ xforms;
     const HitRec* __restrict__ hitrec;     // indexed by primitive
     const rtw_light* __restrict__ lights;
-    const BvhNode* __restrict__ nodes;
-    const int32_t* __restrict__ tree_prims;  // leaf entries -> primitive index
+    const u32x4* __restrict__ nodes;         // 4 vectors per node
+    const u32x4* __restrict__ leaves;        // 2 vectors per leaf record
     const int32_t* __restrict__ order;       // candidate order: volumes (index order) then the rest (index order)
     const BruteGroup* __restrict__ groups;   // small scenes: primitives regrouped by instance transform and kind
     const BruteRec* __restrict__ recs;
@@ -352,6 +346,7 @@ struct DScene {
     // BVH: leading (breadth-first) nodes staged in LDS behind the traversal stacks; noise_lds_data: word offset of the
     // noise tables staged in LDS, or -1
     int32_t n_lds_nodes, stack_depth, has_tex, noise_lds_data;
+    int32_t n_lds_leaves, stack_wide;        // leaf records staged in LDS; 1 = 32-bit stack entries (references beyond 16 bits)
     int32_t estimator;                       // rtw_estimator of the current render (set per call, not at upload)
     float ray_tmin, probe_eps;               // 1e-6 / 5e-5 as the reference; 1e-3 for the corrected estimators
     const rtw_light* __restrict__ clights;   // RTW_EST_CORRECTED: the light list moved onto the emitting rectangles
@@ -408,52 +403,43 @@ RTW_DEV BruteRec load_rec(const DScene& sc, int i) {
     r.e = __uint_as_float(q[4]); r.prim = (int)q[5]; r.pad0 = 0; r.pad1 = 0;
     return r;
 }
-#ifndef RTW_LDS_NODE_VECS
-#define RTW_LDS_NODE_VECS 5
-#endif
-constexpr int kLdsNodeVecs = RTW_LDS_NODE_VECS;  // 16-byte vectors per tree node in the LDS copy (4 = packed)
-// Per-thread traversal memory: this thread's column of the LDS stack and the block's LDS copy of the top of the tree.
+static constexpr uint32_t kBvhDone = 0xffffffffu;  // a reference with count bits = 3: neither an inner node nor a leaf that exists
+// Per-thread traversal memory: this thread's column of the LDS stack, the block's LDS copy of the top of the tree and
+// of the first leaf records. Stack entries are 16 bits wide whenever every reference of the tree fits (the LDS the
+// stacks take decides how many waves a CU holds), else 32.
 struct TravMem {
-    uint32_t* stack;
+    uint16_t* stack16;
+    uint32_t* stack32;
     uint32_t stride;
     const u32x4* nodes;   // LDS, n_nodes * 4 vectors
     uint32_t n_nodes;
+    const u32x4* leaves;  // LDS, n_leaves * 2 vectors
+    uint32_t n_leaves;
+    bool wide;
 };
 
 // Every thread of the block calls this once before its first traverse<> (it holds a barrier).
 RTW_DEV TravMem trav_mem(const DScene& sc, uint32_t* lds, uint32_t block, uint32_t tid) {
     TravMem tm;
-    tm.stack = lds + tid;
+    tm.wide = sc.stack_wide != 0;
+    // row 0 of a column holds "nothing left" for good (a pop of the empty stack reads it), the stack proper starts at row 1
+    if (tm.wide) lds[tid] = kBvhDone; else ((uint16_t*)lds)[tid] = 0xffffu;
+    tm.stack16 = (uint16_t*)lds + block + tid;
+    tm.stack32 = lds + block + tid;
     tm.stride = block;
-    u32x4* cache = (u32x4*)(lds + (uint32_t)sc.stack_depth * block);
+    const uint32_t stack_words = tm.wide ? (uint32_t)sc.stack_depth * block : ((uint32_t)sc.stack_depth * block + 1u) / 2u;
+    u32x4* cache = (u32x4*)(lds + ((stack_words + 3u) & ~3u));
     tm.nodes = cache;
     tm.n_nodes = (uint32_t)sc.n_lds_nodes;
+    tm.leaves = cache + tm.n_nodes * 4u;
+    tm.n_leaves = (uint32_t)sc.n_lds_leaves;
     if (tm.n_nodes) {
-        // LDS copy with a stride of kLdsNodeVecs 16-byte vectors per node: at the natural stride of 4 (64 B) the four
-        // ds_read_b128 of a node fall on only four bank groups, whatever the node (a 4-way conflict for 16 lanes at 16
-        // different nodes); 5 (80 B) spreads consecutive nodes over all sixteen 4-bank groups
-        const u32x4* src = (const u32x4*)sc.nodes;
-        for (uint32_t i = tid; i < tm.n_nodes * 4u; i += block) cache[(i >> 2) * kLdsNodeVecs + (i & 3u)] = src[i];
+        const uint32_t nv = tm.n_nodes * 4u, nl = tm.n_leaves * 2u;
+        for (uint32_t i = tid; i < nv; i += block) cache[i] = sc.nodes[i];
+        for (uint32_t i = tid; i < nl; i += block) cache[nv + i] = sc.leaves[i];
         __syncthreads();
     }
     return tm;
-}
-
-RTW_DEV BvhNode load_node(const DScene& sc, const TravMem& tm, uint32_t i) {
-    u32x4 a, b, c, d;
-    if (i < tm.n_nodes) {
-        const u32x4* q = tm.nodes + (uint32_t)kLdsNodeVecs * i;
-        a = q[0]; b = q[1]; c = q[2]; d = q[3];
-    } else {
-        const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + i);
-        a = q[0]; b = q[1]; c = q[2]; d = q[3];
-    }
-    BvhNode n;
-    n.lmn[0] = __uint_as_float(a.x); n.lmn[1] = __uint_as_float(a.y); n.lmn[2] = __uint_as_float(a.z); n.lref = a.w;
-    n.lmx[0] = __uint_as_float(b.x); n.lmx[1] = __uint_as_float(b.y); n.lmx[2] = __uint_as_float(b.z); n.pad0 = 0;
-    n.rmn[0] = __uint_as_float(c.x); n.rmn[1] = __uint_as_float(c.y); n.rmn[2] = __uint_as_float(c.z); n.rref = c.w;
-    n.rmx[0] = __uint_as_float(d.x); n.rmx[1] = __uint_as_float(d.y); n.rmx[2] = __uint_as_float(d.z); n.pad1 = 0;
-    return n;
 }
 
 // geometry/movingSphere.cu:33-39
@@ -579,46 +565,105 @@ RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, v3 inv, float tmin, flo
     }
 }
 
-// ---- BVH2 walk, shared by traverse<> and the refilling trace kernel (rtw_kernels.h k_trace_bvh) ----
-static constexpr uint32_t kBvhDone = 0xffffffffu;  // not an inner reference (count bits = 3), not a leaf that exists
+// ---- tree walk, shared by traverse<> and the refilling trace kernels (rtw_kernels.h k_trace_bvh, k_path_tree) ----
 
+// sp is the byte offset of the top of this thread's stack column (0 = empty). A pop never branches: under the stack
+// lies a row that says "nothing left" (16-bit entries are sign-extended, so 0xffff reads as kBvhDone; references stay
+// below 0x8000 in that mode), and a walk that has popped it is over.
+RTW_DEV uint32_t bvh_top(const TravMem& tm, int sp) {
+    if (tm.wide) return *(const uint32_t*)((const char*)tm.stack32 + (sp - (int)(tm.stride * 4u)));
+    return (uint32_t)(int32_t)*(const int16_t*)((const char*)tm.stack16 + (sp - (int)(tm.stride * 2u)));
+}
 RTW_DEV uint32_t bvh_pop(const TravMem& tm, int& sp) {
-    if (sp == 0) return kBvhDone;
-    sp--;
-    return tm.stack[sp * tm.stride];
+    const uint32_t r = bvh_top(tm, sp);
+    sp -= (int)(tm.stride * (tm.wide ? 4u : 2u));
+    return r;
 }
 
-// One step through inner node `cur`: slab tests of both children against [tmin, best_t], nearer child first,
-// the other one pushed. Returns the next reference (inner or leaf), or kBvhDone when nothing is left.
+// One step through inner node `cur`: the four children's boxes against [tmin, best_t]; the nearest child that is hit is
+// entered, the others are pushed. Returns the next reference (inner or leaf), or kBvhDone when nothing is left.
+// The boxes only cull (exact hits are decided by the primitive tests), so everything here may be approximate as long as
+// it errs towards "hit": planes are p + q * step on the node's grid (rounded outwards by the builder, and the primitive
+// bounds under them are padded by 1e-4), plane distances q * (step / d) + (p - o) / d with the reciprocal clamped to
+// +-1e18 (a zero direction component then gives huge finite distances of the right sign instead of inf - inf).
 RTW_DEV uint32_t bvh_inner_step(const DScene& sc, const TravMem& tm, const v3 o, const v3 inv, float tmin, float best_t, uint32_t cur, int& sp) {
-    const BvhNode nd = load_node(sc, tm, cur);
-    float tn0, tn1;
-    bool h0, h1;
-    {
-        float ax = (nd.lmn[0] - o.x) * inv.x, bx = (nd.lmx[0] - o.x) * inv.x;
-        float ay = (nd.lmn[1] - o.y) * inv.y, by = (nd.lmx[1] - o.y) * inv.y;
-        float az = (nd.lmn[2] - o.z) * inv.z, bz = (nd.lmx[2] - o.z) * inv.z;
-        tn0 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
-        float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
-        h0 = tn0 <= tfar * 1.00001f;
+    const uint32_t i = cur >> 2;
+    u32x4 q0, q1, q2, q3;
+    if (i < tm.n_nodes) {
+        const u32x4* q = tm.nodes + 4u * i;
+        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+    } else {
+        const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + 4u * i);
+        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
     }
-    {
-        float ax = (nd.rmn[0] - o.x) * inv.x, bx = (nd.rmx[0] - o.x) * inv.x;
-        float ay = (nd.rmn[1] - o.y) * inv.y, by = (nd.rmx[1] - o.y) * inv.y;
-        float az = (nd.rmn[2] - o.z) * inv.z, bz = (nd.rmx[2] - o.z) * inv.z;
-        tn1 = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin));
-        float tfar = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), best_t));
-        h1 = tn1 <= tfar * 1.00001f;
+    // q0 = p.x p.y p.z step.x, q1 = lo.x lo.y lo.z hi.x, q2 = hi.y hi.z step.y step.z, q3 = the references
+    const float ix = __builtin_amdgcn_fmed3f(inv.x, -1.0e18f, 1.0e18f), iy = __builtin_amdgcn_fmed3f(inv.y, -1.0e18f, 1.0e18f),
+                iz = __builtin_amdgcn_fmed3f(inv.z, -1.0e18f, 1.0e18f);
+    const float ax = (__uint_as_float(q0.x) - o.x) * ix, ay = (__uint_as_float(q0.y) - o.y) * iy, az = (__uint_as_float(q0.z) - o.z) * iz;
+    const float bx = __uint_as_float(q0.w) * ix, by = __uint_as_float(q2.z) * iy, bz = __uint_as_float(q2.w) * iz;
+    // the plane a ray meets first on an axis is lo when it travels upwards
+    const uint32_t nx = ix < 0.0f ? q1.w : q1.x, fx = ix < 0.0f ? q1.x : q1.w;
+    const uint32_t ny = iy < 0.0f ? q2.x : q1.y, fy = iy < 0.0f ? q1.y : q2.x;
+    const uint32_t nz = iz < 0.0f ? q2.y : q1.z, fz = iz < 0.0f ? q1.z : q2.y;
+    uint32_t key[4];
+#define RTW_Q4_CHILD(C_, REF_)                                                                                                   \
+    {                                                                                                                            \
+        const float tnx = fma_((float)((nx >> (8 * C_)) & 0xffu), bx, ax), tfx = fma_((float)((fx >> (8 * C_)) & 0xffu), bx, ax); \
+        const float tny = fma_((float)((ny >> (8 * C_)) & 0xffu), by, ay), tfy = fma_((float)((fy >> (8 * C_)) & 0xffu), by, ay); \
+        const float tnz = fma_((float)((nz >> (8 * C_)) & 0xffu), bz, az), tfz = fma_((float)((fz >> (8 * C_)) & 0xffu), bz, az); \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));                                \
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, best_t));                              \
+        const bool hit = tn <= tf && (REF_) != kBvhDone;                                                                        \
+        key[C_] = hit ? ((__float_as_uint(tn) & ~3u) | (uint32_t)C_) : 0xffffffffu;                                             \
     }
-    if (h0 && h1) {
-        const bool first0 = tn0 <= tn1;
-        tm.stack[sp * tm.stride] = first0 ? nd.rref : nd.lref;
-        sp++;
-        return first0 ? nd.lref : nd.rref;
+    RTW_Q4_CHILD(0, q3.x) RTW_Q4_CHILD(1, q3.y) RTW_Q4_CHILD(2, q3.z) RTW_Q4_CHILD(3, q3.w)
+#undef RTW_Q4_CHILD
+    // tn >= tmin > 0, so the distances order as unsigned integers; the slot in the low bits makes the keys distinct
+    const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+    // every slot is stored at the top of the stack and the top moves past the ones that stay (hit, not the nearest): no
+    // divergent branch per slot; the column has one entry of slack for the last store
+    const bool p0 = key[0] != 0xffffffffu && key[0] != kmin, p1 = key[1] != 0xffffffffu && key[1] != kmin,
+               p2 = key[2] != 0xffffffffu && key[2] != kmin, p3 = key[3] != 0xffffffffu && key[3] != kmin;
+    if (tm.wide) {
+        char* b = (char*)tm.stack32;
+        const int st = (int)(tm.stride * 4u);
+        *(uint32_t*)(b + sp) = q3.x; sp += p0 ? st : 0;
+        *(uint32_t*)(b + sp) = q3.y; sp += p1 ? st : 0;
+        *(uint32_t*)(b + sp) = q3.z; sp += p2 ? st : 0;
+        *(uint32_t*)(b + sp) = q3.w; sp += p3 ? st : 0;
+    } else {
+        char* b = (char*)tm.stack16;
+        const int st = (int)(tm.stride * 2u);
+        *(uint16_t*)(b + sp) = (uint16_t)q3.x; sp += p0 ? st : 0;
+        *(uint16_t*)(b + sp) = (uint16_t)q3.y; sp += p1 ? st : 0;
+        *(uint16_t*)(b + sp) = (uint16_t)q3.z; sp += p2 ? st : 0;
+        *(uint16_t*)(b + sp) = (uint16_t)q3.w; sp += p3 ? st : 0;
     }
-    if (h0) return nd.lref;
-    if (h1) return nd.rref;
-    return bvh_pop(tm, sp);
+    const uint32_t top = bvh_top(tm, sp);
+    const bool none = kmin == 0xffffffffu;
+    sp -= none ? (int)(tm.stride * (tm.wide ? 4u : 2u)) : 0;
+    const uint32_t slot = kmin & 3u;
+    return none ? top : slot == 0u ? q3.x : slot == 1u ? q3.y : slot == 2u ? q3.z : q3.w;
+}
+
+// Leaf record `k` of the tree as a primitive record: spheres and rectangles come whole from the 32-byte record (their
+// intersection programs read p[0..4] only), other kinds from the primitive table.
+RTW_DEV rtw_prim load_leaf(const DScene& sc, const TravMem& tm, uint32_t k, int& prim) {
+    u32x4 a, b;
+    if (k < tm.n_leaves) { a = tm.leaves[2u * k]; b = tm.leaves[2u * k + 1u]; }
+    else {
+        const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.leaves + 2u * k);
+        a = q[0]; b = q[1];
+    }
+    prim = (int)b.y;
+    const int type = (int)(b.z & 0xffu);
+    if (type != RTW_PRIM_SPHERE && !(type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_RECT_Z)) return load_prim(sc, prim);
+    rtw_prim r;
+    r.type = type; r.material = 0; r.xform = (int)(b.z >> 8); r.flip = 0;
+    r.p[0] = __uint_as_float(a.x); r.p[1] = __uint_as_float(a.y); r.p[2] = __uint_as_float(a.z); r.p[3] = __uint_as_float(a.w);
+    r.p[4] = __uint_as_float(b.x);
+    for (int j = 5; j < 12; j++) r.p[j] = 0.0f;
+    return r;
 }
 
 // Conservative: false only when the ray certainly stays outside the scene bounds (NaNs from 0 * inf answer "may hit").
@@ -868,19 +913,19 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
         if (ANY_HIT) return;                                                                         \
     }
     if (sc.n_tree <= 0) return;
-    // BVH2, "while-while" walk: a tight loop descends through inner nodes (one 64-byte record per step carries
-    // both children's boxes), leaves wait on the per-lane LDS stack column like inner nodes and are tested when
+    // "while-while" walk of the 4-wide tree: a tight loop descends through inner nodes (one 64-byte record per step
+    // carries four children's boxes), leaves wait on the per-lane LDS stack column like inner nodes and are tested when
     // they come up. The boxes only cull, so the visiting order does not change the result.
     const v3 inv = recip3(d);
     int sp = 0;
     uint32_t cur = 0;
     for (;;) {
-        while ((cur >> 30) == 0u) cur = bvh_inner_step(sc, tm, o, inv, tmin, best_t, cur, sp);
+        while ((cur & 3u) == 0u) cur = bvh_inner_step(sc, tm, o, inv, tmin, best_t, cur, sp);
         if (cur == kBvhDone) break;
-        const uint32_t first = cur & 0x3fffffffu, cnt = cur >> 30;
+        const uint32_t first = cur >> 2, cnt = cur & 3u;
         for (uint32_t k = 0; k < cnt; k++) {
-            const int pi = load_i32(sc.tree_prims + first + k);
-            const rtw_prim pr = load_prim(sc, pi);
+            int pi;
+            const rtw_prim pr = load_leaf(sc, tm, first + k, pi);
             v3 po, pd, mt;
             object_ray(sc, pr, o, d, ray_time, po, pd, mt);
             v3 pinv = inv;

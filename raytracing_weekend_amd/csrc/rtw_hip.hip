@@ -55,6 +55,7 @@ struct rtw_ctx {
     void* d_scene = nullptr;   // one allocation holding all scene tables
     int stack_depth = 0;
     size_t lds_bytes = 0;
+    size_t n_tree_nodes = 0, n_tree_leaves = 0;  // 4-wide nodes and leaf records of the uploaded scene's tree
     // render pool
     // Two independent "lanes" (stream + path pool): consecutive batches alternate between them so that the
     // bandwidth-bound kernels of one batch overlap the compute- and latency-bound kernels of the other.
@@ -227,6 +228,9 @@ struct Tuning {
     bool split_media = true;  // RTW_SPLIT_MEDIA=0: scenes with media keep every bounce in k_bounce
     int brute_max = kBruteMaxPrims;
     size_t lds_kb = 16;
+    int trace_block = 256;       // threads per workgroup of k_trace_bvh (256, 512, 1024)
+    size_t trace_lds_kb = 16;    // its LDS budget: stacks + tree nodes + leaf records
+    int trace_waves = 6;         // waves per SIMD it is launched for
     int stagger_pct = 50;
     int tail_group = 2;
     int path = 1;
@@ -237,6 +241,7 @@ struct Tuning {
     int path_grid_mult = 0;
     size_t blocksum_bytes = (size_t)16 << 30;
     bool kernel_timing = true;
+    bool verbose = false;  // RTW_VERBOSE=1: table sizes at upload (stderr)
 };
 Tuning read_tuning() {
     Tuning t;
@@ -255,6 +260,9 @@ Tuning read_tuning() {
     if (geti("RTW_SPLIT_MEDIA", v)) t.split_media = v != 0;
     if (geti("RTW_BRUTE_MAX", v)) t.brute_max = (int)v;
     if (geti("RTW_LDS_KB", v)) t.lds_kb = (size_t)std::max<long long>(0, v);
+    if (geti("RTW_TRACE_BLOCK", v) && (v == 256 || v == 512 || v == 1024)) t.trace_block = (int)v;
+    if (geti("RTW_TRACE_LDS_KB", v)) t.trace_lds_kb = (size_t)std::max<long long>(0, std::min<long long>(150, v));
+    if (geti("RTW_TRACE_WAVES", v)) t.trace_waves = (int)std::max<long long>(1, std::min<long long>(8, v));
     if (geti("RTW_TAIL_GROUP", v)) t.tail_group = (int)std::max<long long>(1, std::min<long long>(64, v));
     if (geti("RTW_STAGGER", v)) t.stagger_pct = (int)std::max<long long>(0, std::min<long long>(99, v));
     if (geti("RTW_PATH", v)) t.path = (int)std::max<long long>(0, std::min<long long>(2, v));
@@ -265,11 +273,24 @@ Tuning read_tuning() {
     if (geti("RTW_PATH_GRID_MULT", v)) t.path_grid_mult = (int)std::max<long long>(1, std::min<long long>(16, v));
     if (geti("RTW_BLOCKSUM_BYTES", v) && v >= (1 << 16)) t.blocksum_bytes = (size_t)v;
     if (geti("RTW_KERNEL_TIMING", v)) t.kernel_timing = v != 0;
+    if (geti("RTW_VERBOSE", v)) t.verbose = v != 0;
     return t;
 }
 
+// LDS of a tree-walking workgroup of `block` threads: the traversal stacks (16-bit entries unless a reference needs more),
+// then as many leading (breadth-first) tree nodes and, once all nodes are in, leaf records as fit `budget` bytes.
+size_t tree_lds_layout(size_t n_nodes_all, size_t n_leaves_all, int stack_depth, bool wide, size_t block, size_t budget, int32_t& n_nodes, int32_t& n_leaves) {
+    const size_t stack_words = wide ? (size_t)stack_depth * block : ((size_t)stack_depth * block + 1) / 2;
+    const size_t stack_bytes = ((stack_words + 3) & ~size_t(3)) * 4;
+    size_t room = budget > stack_bytes ? budget - stack_bytes : 0;
+    n_nodes = (int32_t)std::min<size_t>(n_nodes_all, room / sizeof(rtwbvh::Q4Node));
+    room -= (size_t)n_nodes * sizeof(rtwbvh::Q4Node);
+    n_leaves = (size_t)n_nodes == n_nodes_all ? (int32_t)std::min<size_t>(n_leaves_all, room / sizeof(rtwbvh::LeafRec)) : 0;
+    return stack_bytes + (size_t)n_nodes * sizeof(rtwbvh::Q4Node) + (size_t)n_leaves * sizeof(rtwbvh::LeafRec);
+}
+
 enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE, LK_PATH = RTW_K_PATH, LK_PATH_TREE = RTW_K_COUNT };
-void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s) {
+void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s, int block = kBlock) {
     const bool lcg = rng_kind == RTW_RNG_TEA_LCG;
     // kernels that shade exist in four instantiations: RNG kind x "some material has a non-constant texture"
     const bool tex = a.sc.has_tex != 0;
@@ -284,7 +305,11 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
     case LK_FIRST: RTW_LAUNCH_SHADING(k_first, lds); break;
     case LK_SHADE: RTW_LAUNCH_SHADING(k_shade, 0); break;
     case LK_TRACE:
-        if (a.sc.use_bvh) hipLaunchKernelGGL(k_trace_bvh, dim3(grid), dim3(kBlock), lds, s, a);
+        if (a.sc.use_bvh) {
+            if (block == 1024) hipLaunchKernelGGL((k_trace_bvh<1024>), dim3(grid), dim3(1024), lds, s, a);
+            else if (block == 512) hipLaunchKernelGGL((k_trace_bvh<512>), dim3(grid), dim3(512), lds, s, a);
+            else hipLaunchKernelGGL((k_trace_bvh<256>), dim3(grid), dim3(256), lds, s, a);
+        }
         else if (a.sc.n_generic == 0) hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(kBlock), lds, s, a);
         else hipLaunchKernelGGL((k_trace<false>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
@@ -586,7 +611,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     rtwbvh::Bvh bvh;
     if (use_bvh) {
         bvh = rtwbvh::build_bvh(prims.data(), h.n_prims, xforms.data());
-        if (bvh.max_depth > 60) return fail(c, RTW_ERR_UNSUPPORTED, "BVH deeper than the LDS traversal stack");
+        if (bvh.stack_need > 95) return fail(c, RTW_ERR_UNSUPPORTED, "tree deeper than the LDS traversal stack");
+        if (bvh.max_exp > 60) return fail(c, RTW_ERR_UNSUPPORTED, "scene extent beyond 1e20");
     }
 
     // one device allocation, 256-byte aligned sub-tables
@@ -597,8 +623,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     size_t o_lights = al(o_shade + shade.size() * sizeof(HitRec));
     size_t o_clights = al(o_lights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
     size_t o_nodes = al(o_clights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
-    size_t o_tree = al(o_nodes + std::max<size_t>(1, bvh.wide.size()) * sizeof(BvhNode));
-    size_t o_order = al(o_tree + std::max<size_t>(1, bvh.prim_order.size()) * sizeof(int32_t));
+    size_t o_tree = al(o_nodes + std::max<size_t>(1, bvh.q4.size()) * sizeof(rtwbvh::Q4Node));
+    size_t o_order = al(o_tree + std::max<size_t>(1, bvh.leaves.size()) * sizeof(rtwbvh::LeafRec));
     size_t o_groups = al(o_order + std::max<size_t>(1, order.size()) * sizeof(int32_t));
     size_t o_recs = al(o_groups + std::max<size_t>(1, groups.size()) * sizeof(BruteGroup));
     size_t o_texs = al(o_recs + (recs.size() + 1) * sizeof(BruteRec));  // + 1: traverse_brute reads one record ahead
@@ -611,9 +637,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!shade.empty()) memcpy(stage.data() + o_shade, shade.data(), shade.size() * sizeof(HitRec));
     if (!lights.empty()) memcpy(stage.data() + o_lights, lights.data(), lights.size() * sizeof(rtw_light));
     if (!clights.empty()) memcpy(stage.data() + o_clights, clights.data(), clights.size() * sizeof(rtw_light));
-    static_assert(sizeof(BvhNode) == sizeof(rtwbvh::WideNode), "node layout");
-    if (!bvh.wide.empty()) memcpy(stage.data() + o_nodes, bvh.wide.data(), bvh.wide.size() * sizeof(BvhNode));
-    if (!bvh.prim_order.empty()) memcpy(stage.data() + o_tree, bvh.prim_order.data(), bvh.prim_order.size() * sizeof(int32_t));
+    if (!bvh.q4.empty()) memcpy(stage.data() + o_nodes, bvh.q4.data(), bvh.q4.size() * sizeof(rtwbvh::Q4Node));
+    if (!bvh.leaves.empty()) memcpy(stage.data() + o_tree, bvh.leaves.data(), bvh.leaves.size() * sizeof(rtwbvh::LeafRec));
     if (!order.empty()) memcpy(stage.data() + o_order, order.data(), order.size() * sizeof(int32_t));
     if (!groups.empty()) memcpy(stage.data() + o_groups, groups.data(), groups.size() * sizeof(BruteGroup));
     if (!recs.empty()) memcpy(stage.data() + o_recs, recs.data(), recs.size() * sizeof(BruteRec));
@@ -635,8 +660,8 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.lights = (const rtw_light*)(d + o_lights);
     sc.clights = (const rtw_light*)(d + o_clights);
     sc.estimator = RTW_EST_REFERENCE; sc.ray_tmin = 1e-6f; sc.probe_eps = 500 * 1.0e-7f;  // set per render
-    sc.nodes = (const BvhNode*)(d + o_nodes);
-    sc.tree_prims = (const int32_t*)(d + o_tree);
+    sc.nodes = (const u32x4*)(d + o_nodes);
+    sc.leaves = (const u32x4*)(d + o_tree);
     sc.order = (const int32_t*)(d + o_order);
     sc.groups = (const BruteGroup*)(d + o_groups);
     sc.recs = (const BruteRec*)(d + o_recs);
@@ -674,19 +699,19 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.cam = h.camera;
     sc.pdf = h.pdf;
     sc.cam_type = h.camera_type;
-    // LDS per block: the traversal stacks, then as many leading (breadth-first) tree nodes as fit the budget
-    c->stack_depth = use_bvh ? bvh.max_depth + 2 : 0;
+    // LDS per block: the traversal stacks (16-bit entries when every reference fits), then as many leading (breadth-first)
+    // tree nodes and, behind them, leaf records as fit the budget
+    c->stack_depth = use_bvh ? bvh.stack_need + 1 : 0;  // + the row under the stack that ends a walk
     sc.stack_depth = c->stack_depth;
-    sc.n_lds_nodes = 0;
+    sc.n_lds_nodes = 0; sc.n_lds_leaves = 0; sc.stack_wide = 0;
+    c->lds_bytes = 0;
     if (use_bvh) {
-        // Measured on scene 1 (13 levels, 318 nodes): occupancy is worth more than LDS-resident nodes - 16 KB
-        // (the stacks plus the top few levels) beats 22 / 30 / 36 KB by 10-25 %; the work-list statics add 9.3 KB.
-        const size_t budget_kb = tune.lds_kb;
-        const size_t stack_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t);
-        const size_t room = budget_kb * 1024 > stack_bytes ? budget_kb * 1024 - stack_bytes : 0;
-        sc.n_lds_nodes = (int32_t)std::min<size_t>(bvh.wide.size(), room / ((size_t)kLdsNodeVecs * 16));
+        sc.stack_wide = (std::max(bvh.q4.size(), bvh.leaves.size()) << 2) >= 0x7ff0u ? 1 : 0;  // 16-bit entries are read sign-extended
+        c->n_tree_nodes = bvh.q4.size(); c->n_tree_leaves = bvh.leaves.size();
+        c->lds_bytes = tree_lds_layout(c->n_tree_nodes, c->n_tree_leaves, c->stack_depth, sc.stack_wide != 0, kBlock, tune.lds_kb * 1024, sc.n_lds_nodes, sc.n_lds_leaves);
+        if (tune.verbose) fprintf(stderr, "[rtw] tree: %zu nodes, %zu leaf records, stack %d x %d bit; LDS %zu B: %d nodes, %d leaf records\n",
+                                  bvh.q4.size(), bvh.leaves.size(), c->stack_depth, sc.stack_wide ? 32 : 16, c->lds_bytes, sc.n_lds_nodes, sc.n_lds_leaves);
     }
-    c->lds_bytes = (size_t)c->stack_depth * kBlock * sizeof(uint32_t) + (size_t)sc.n_lds_nodes * (size_t)kLdsNodeVecs * 16;
     c->sc = sc;
     c->has_scene = true;
     return RTW_OK;
@@ -736,9 +761,9 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
     };
     struct Timed { int kind; hipEvent_t a, b; };
     std::vector<Timed> ev_k;
-    auto timed_launch = [&](hipStream_t ls, int kind, const KArgs& ka, int grid_, size_t lds_) -> hipError_t {
+    auto timed_launch = [&](hipStream_t ls, int kind, const KArgs& ka, int grid_, size_t lds_, int block_ = kBlock) -> hipError_t {
         if (!timing) {
-            launch(kind, P->rng_kind, ka, grid_, lds_, ls);
+            launch(kind, P->rng_kind, ka, grid_, lds_, ls, block_);
             return hipSuccess;
         }
         Timed t{kind == LK_PATH_TREE ? (int)RTW_K_PATH : kind, nullptr, nullptr};
@@ -746,7 +771,7 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         if (er == hipSuccess) er = new_event(t.b);
         if (er == hipSuccess) er = hipEventRecord(t.a, ls);
         if (er != hipSuccess) return er;
-        launch(kind, P->rng_kind, ka, grid_, lds_, ls);
+        launch(kind, P->rng_kind, ka, grid_, lds_, ls, block_);
         ev_k.push_back(t);
         return hipEventRecord(t.b, ls);
     };
@@ -907,6 +932,23 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         const size_t g = grid_for(paths);
         return ((chunks + g - 1) / g + 2) * (size_t)kBlock;
     };
+    // k_trace_bvh: large workgroups share one LDS copy of the tree (nodes, then leaf records) between more waves
+    const int trace_block = tune.trace_block;
+    int32_t trace_nodes = 0, trace_leaves = 0;
+    size_t trace_lds = 0;
+    int trace_grid = 0;
+    if (c->sc.use_bvh) {
+        trace_lds = tree_lds_layout(c->n_tree_nodes, c->n_tree_leaves, c->stack_depth, c->sc.stack_wide != 0, (size_t)trace_block, tune.trace_lds_kb * 1024,
+                                    trace_nodes, trace_leaves);
+        const size_t per_wg = trace_lds + (kMaxRegions + 1 + (size_t)trace_block) * 4 + 64;
+        const size_t by_lds = std::max<size_t>(1, (size_t)160 * 1024 / per_wg);
+        const size_t by_waves = std::max<size_t>(1, (size_t)(4 * tune.trace_waves) / ((size_t)trace_block / 64));
+        trace_grid = (int)((size_t)c->n_cu * std::min(by_lds, by_waves));
+        if (trace_lds > 48 * 1024) {  // beyond the default dynamic-LDS limit of a launch
+            const void* f = trace_block == 1024 ? (const void*)k_trace_bvh<1024> : trace_block == 512 ? (const void*)k_trace_bvh<512> : (const void*)k_trace_bvh<256>;
+            HIP_TRY(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trace_lds));
+        }
+    }
     const uint32_t regions_max = grid_for(paths_max);
     const size_t region_cap_max = cap_for(paths_max);
     bool split_first = false;
@@ -948,7 +990,7 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
     HIP_TRY_C(hipEventRecord(ev_begin, s));
     HIP_TRY_C(hipMemsetAsync(c->accum, 0, npix * sizeof(float4), s));
     HIP_TRY_C(hipMemsetAsync(c->part, 0, npix * sizeof(float4), s));
-    HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, kStatRows * 8 * sizeof(unsigned long long), s));
+    HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, (kStatRows + 1) * 8 * sizeof(unsigned long long), s));
 
     if (P->max_depth > 0) {
         // the lanes start once the accumulators are cleared
@@ -1000,7 +1042,13 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
                 a.depth = (uint32_t)st.depth;
                 a.n_iter = (uint32_t)st.n_iter;
                 if (st.kind == LK_TRACE) {
-                    HIP_TRY_C(timed_launch(ls, LK_TRACE, a, grid, lds));
+                    if (c->sc.use_bvh) {  // its own workgroup size, LDS image and grid: waves own streams of chunks, not regions
+                        KArgs at = a;
+                        at.sc.n_lds_nodes = trace_nodes; at.sc.n_lds_leaves = trace_leaves;
+                        HIP_TRY_C(timed_launch(ls, LK_TRACE, at, trace_grid, trace_lds, trace_block));
+                    } else {
+                        HIP_TRY_C(timed_launch(ls, LK_TRACE, a, grid, lds));
+                    }
                 } else {
                     a.out = L.buf[cur ^ 1];
                     a.hit_out = L.hit[cur ^ 1];
@@ -1046,7 +1094,14 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
     }
 #endif
 #ifdef RTW_TRACE_COUNT
-    fprintf(stderr, "[rtw] k_trace_bvh: rays %llu inner steps %llu prim tests %llu outer iterations(wave) %llu\n", hs[2 + RTW_K_TRACE], hs[6], hs[7], hs[2 + RTW_K_BOUNCE]);
+    {
+        unsigned long long w[2];
+        HIP_TRY_C(hipMemcpy(w, c->d_stats + kStatRows * 8, sizeof w, hipMemcpyDeviceToHost));
+        const double rays = (double)hs[2 + RTW_K_TRACE];
+        fprintf(stderr, "[rtw] k_trace_bvh: rays %.4g; per ray: node visits %.2f, primitive tests %.2f; wave steps per 64 rays: inner %.2f (lanes busy %.2f), leaf %.2f (lanes busy %.2f), outer %.2f\n",
+                rays, (double)hs[6] / rays, (double)hs[7] / rays, (double)w[0] * 64.0 / rays, (double)hs[6] / ((double)w[0] * 64.0), (double)w[1] * 64.0 / rays,
+                (double)hs[7] / ((double)w[1] * 64.0), (double)hs[2 + RTW_K_BOUNCE] * 64.0 / rays);
+    }
 #endif
     if (stats) {
         float ms = 0.f;

@@ -128,13 +128,16 @@ struct WorkList {
     uint32_t* pref;  // [kMaxRegions+1]: (exclusive prefix of chunk counts) << 8 | (live paths of the region) & 255
     uint32_t total_chunks;
 };
-#define RTW_WORKLIST_SHARED                        \
+#define RTW_WORKLIST_SHARED_T(BLOCK_)               \
     __shared__ uint32_t s_pref[kMaxRegions + 1];   \
-    __shared__ uint32_t s_part[kBlock];
+    __shared__ uint32_t s_part[BLOCK_];
+#define RTW_WORKLIST_SHARED RTW_WORKLIST_SHARED_T(kBlock)
 
+// BLOCK = threads of the calling workgroup (the chunks of the list are kBlock slots whatever the workgroup's size)
+template <uint32_t BLOCK = kBlock>
 RTW_DEV WorkList worklist_init(const uint32_t* cnt_in, uint32_t n_regions, uint32_t* s_pref, uint32_t* s_part) {
     const uint32_t tid = threadIdx.x;
-    constexpr uint32_t kPer = kMaxRegions / kBlock;
+    constexpr uint32_t kPer = kMaxRegions / BLOCK;
     uint32_t loc[kPer], low[kPer];
     uint32_t sum = 0;
 #pragma unroll
@@ -147,7 +150,7 @@ RTW_DEV WorkList worklist_init(const uint32_t* cnt_in, uint32_t n_regions, uint3
     }
     s_part[tid] = sum;
     __syncthreads();
-    for (uint32_t off = 1; off < kBlock; off <<= 1) {
+    for (uint32_t off = 1; off < BLOCK; off <<= 1) {
         const uint32_t v = tid >= off ? s_part[tid - off] : 0u;
         __syncthreads();
         s_part[tid] += v;
@@ -156,7 +159,7 @@ RTW_DEV WorkList worklist_init(const uint32_t* cnt_in, uint32_t n_regions, uint3
     const uint32_t excl = s_part[tid] - sum;
 #pragma unroll
     for (uint32_t j = 0; j < kPer; j++) s_pref[tid * kPer + j] = ((excl + loc[j]) << 8) | low[j];
-    if (tid == kBlock - 1) s_pref[kMaxRegions] = s_part[tid] << 8;
+    if (tid == BLOCK - 1) s_pref[kMaxRegions] = s_part[tid] << 8;
     __syncthreads();
     WorkList w;
     w.pref = s_pref; w.total_chunks = s_pref[kMaxRegions] >> 8;
@@ -763,13 +766,14 @@ __global__ void __launch_bounds__(kBlock, DUAL ? 8 : RTW_TRACE_BVH_WAVES) k_trac
 #ifndef RTW_LEAF_BIAS
 #define RTW_LEAF_BIAS 1
 #endif
-__global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const KArgs A) {
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
-    RTW_WORKLIST_SHARED
+    RTW_WORKLIST_SHARED_T(BLOCK)
     const uint32_t tid = threadIdx.x;
-    const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
-    const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
-    constexpr uint32_t kWaves = kBlock / 64;
+    const TravMem tm = trav_mem(A.sc, s_stack, BLOCK, tid);
+    const WorkList wl = worklist_init<BLOCK>(A.cnt_in, A.n_regions, s_pref, s_part);
+    constexpr uint32_t kWaves = BLOCK / 64;
     const uint32_t stride = gridDim.x * kWaves;
     uint32_t vc = __builtin_amdgcn_readfirstlane(blockIdx.x * kWaves + (tid >> 6));  // this wave's next chunk
     uint32_t chunk_n = 0, next = 0;   // wave-uniform: size of the current chunk, slots of it already handed out
@@ -787,7 +791,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
     NoRng ng;
     const uint32_t root = A.sc.n_tree > 0 ? 0u : kBvhDone;
 #ifdef RTW_TRACE_COUNT
-    uint32_t c_inner = 0, c_prim = 0, c_outer = 0;
+    uint32_t c_inner = 0, c_prim = 0, c_outer = 0, c_winner = 0, c_wleaf = 0;
 #endif
     for (;;) {
 #ifdef RTW_TRACE_COUNT
@@ -842,26 +846,32 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
         // Executing only the majority's branch keeps most lanes busy whatever the mix; the minority waits and grows
         // until it is the majority.
         const uint32_t n_act = (uint32_t)__popcll(__ballot(active));
-        bool at_inner = active && (cur >> 30) == 0u;
+        bool at_inner = active && (cur & 3u) == 0u;
         for (;;) {
             const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
             if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_act - n_in) break;
             if (at_inner) {
                 cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
-                at_inner = (cur >> 30) == 0u;
+                at_inner = (cur & 3u) == 0u;
 #ifdef RTW_TRACE_COUNT
                 c_inner++;
 #endif
             }
+#ifdef RTW_TRACE_COUNT
+            c_winner++;
+#endif
         }
         const bool at_leaf = active && !at_inner && cur != kBvhDone;
+#ifdef RTW_TRACE_COUNT
+        if (__ballot(at_leaf) != 0ull) c_wleaf++;
+#endif
         if (at_leaf) {
-            const uint32_t first = cur & 0x3fffffffu, cnt = cur >> 30;
+            const uint32_t first = cur >> 2, cnt = cur & 3u;
 #ifdef RTW_TRACE_COUNT
             c_prim++;
 #endif
-            const int pi = load_i32(A.sc.tree_prims + first);
-            const rtw_prim pr = load_prim(A.sc, pi);
+            int pi;
+            const rtw_prim pr = load_leaf(A.sc, tm, first, pi);
             v3 po, pd, mt;
             object_ray(A.sc, pr, o, d, ray_time, po, pd, mt);
             v3 pinv = inv;
@@ -875,7 +885,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
                     stop = shadow_phase;
                 }
             }
-            cur = stop ? kBvhDone : (cnt > 1u ? ((first + 1u) | ((cnt - 1u) << 30)) : bvh_pop(tm, sp));
+            cur = stop ? kBvhDone : (cnt > 1u ? (((first + 1u) << 2) | (cnt - 1u)) : bvh_pop(tm, sp));
         }
         if (active) {
             if (cur == kBvhDone) {
@@ -900,7 +910,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TRACE_BVH_WAVES) k_trace_bvh(const
     }
 #ifdef RTW_TRACE_COUNT
     for (int off = 32; off > 0; off >>= 1) { c_inner += __shfl_down(c_inner, off); c_prim += __shfl_down(c_prim, off); }
-    if ((tid & 63u) == 0) { atomicAdd(&A.stats[6], (unsigned long long)c_inner); atomicAdd(&A.stats[7], (unsigned long long)c_prim); atomicAdd(&A.stats[2 + RTW_K_BOUNCE], (unsigned long long)c_outer); }
+    if ((tid & 63u) == 0) { atomicAdd(&A.stats[kStatRows * 8 + 0], (unsigned long long)c_winner); atomicAdd(&A.stats[kStatRows * 8 + 1], (unsigned long long)c_wleaf); atomicAdd(&A.stats[6], (unsigned long long)c_inner); atomicAdd(&A.stats[7], (unsigned long long)c_prim); atomicAdd(&A.stats[2 + RTW_K_BOUNCE], (unsigned long long)c_outer); }
 #endif
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if ((tid & 63u) == 0 && n_rays) atomicAdd(&stat_row(A)[2 + RTW_K_TRACE], (unsigned long long)n_rays);
@@ -1503,13 +1513,13 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
         RTW_MARK("walk_r");
         const bool walking = busy && phase != PH_SHADE;
         const uint32_t n_walk = n_busy - n_shade;
-        bool at_inner = walking && (cur >> 30) == 0u;
+        bool at_inner = walking && (cur & 3u) == 0u;
         for (;;) {
             const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
             if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_walk - n_in) break;
             if (at_inner) {
                 cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
-                at_inner = (cur >> 30) == 0u;
+                at_inner = (cur & 3u) == 0u;
             }
 #ifdef RTW_PHASE_TIMERS
             st_cnt[1]++;
@@ -1521,9 +1531,9 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
         RTW_MARK("walk_s");
         const bool at_leaf = walking && !at_inner && cur != kBvhDone;
         if (at_leaf) {
-            const uint32_t first = cur & 0x3fffffffu, cnt = cur >> 30;
-            const int pi = load_i32(A.sc.tree_prims + first);
-            const rtw_prim pr = load_prim(A.sc, pi);
+            const uint32_t first = cur >> 2, cnt = cur & 3u;
+            int pi;
+            const rtw_prim pr = load_leaf(A.sc, tm, first, pi);
             v3 po, pd, mt;
             object_ray(A.sc, pr, o, wd, wtime, po, pd, mt);
             v3 pinv = inv;
@@ -1537,7 +1547,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
                     stop = phase == PH_PROBE;
                 }
             }
-            cur = stop ? kBvhDone : (cnt > 1u ? ((first + 1u) | ((cnt - 1u) << 30)) : bvh_pop(tm, sp));
+            cur = stop ? kBvhDone : (cnt > 1u ? (((first + 1u) << 2) | (cnt - 1u)) : bvh_pop(tm, sp));
         }
         RTW_MARK("shade_b");
         if (walking && cur == kBvhDone) {
