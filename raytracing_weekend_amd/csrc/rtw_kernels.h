@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
     v3 o = V(0.f, 0.f, 0.f), d = o, inv = o, ldir = o;
     float ltmax = -1.f, tmin = 0.f, ray_time = 0.f, best_t = 0.f, th = 0.f, gt = 0.f;
     int best_prim = -1, prim = -1, sp = 0;
-    uint32_t cur = kBvhDone, occl = 0;
+    uint32_t cur = kBvhDone, pend = 0, occl = 0;
     bool shadow_phase = false;
     NoRng ng;
     const uint32_t root = A.sc.n_tree > 0 ? 0u : kBvhDone;
@@ -828,7 +828,7 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
                         d = ldir; tmin = A.sc.probe_eps; best_t = ltmax; ray_time = 0.0f; shadow_phase = true;
                     }
                     inv = recip3(d);
-                    best_prim = -1; sp = 0; cur = root;
+                    best_prim = -1; sp = 0; cur = root; pend = 0u;
                     if (do_r || ltmax >= 0.0f) {
                         n_rays++;
                         active = true;
@@ -842,16 +842,21 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
             if (__ballot(active) == 0ull) break;
         }
         // One kind of step at a time, chosen by majority: while the lanes standing at inner nodes are not
-        // outnumbered they keep stepping down (a tight loop); then the lanes standing at a leaf test one primitive.
+        // outnumbered they keep stepping down (a tight loop); then the lanes holding a leaf test its primitives.
         // Executing only the majority's branch keeps most lanes busy whatever the mix; the minority waits and grows
-        // until it is the majority.
+        // until it is the majority. A lane that comes to a leaf puts it aside (pend) and walks on with the next
+        // node of its stack: it only has to wait at its second leaf. The nodes it visits meanwhile are culled
+        // against a best_t that has not seen the leaf yet - a few more visits, never a different result.
         const uint32_t n_act = (uint32_t)__popcll(__ballot(active));
+#define RTW_SET_ASIDE if (active && pend == 0u && ((cur & 3u) - 1u) < 2u) { pend = cur; cur = bvh_pop(tm, sp); }
+        RTW_SET_ASIDE
         bool at_inner = active && (cur & 3u) == 0u;
         for (;;) {
             const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
             if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_act - n_in) break;
             if (at_inner) {
                 cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
+                RTW_SET_ASIDE
                 at_inner = (cur & 3u) == 0u;
 #ifdef RTW_TRACE_COUNT
                 c_inner++;
@@ -861,34 +866,39 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
             c_winner++;
 #endif
         }
-        const bool at_leaf = active && !at_inner && cur != kBvhDone;
+        const bool at_leaf = active && pend != 0u;
 #ifdef RTW_TRACE_COUNT
         if (__ballot(at_leaf) != 0ull) c_wleaf++;
 #endif
         if (at_leaf) {
-            const uint32_t first = cur >> 2, cnt = cur & 3u;
-#ifdef RTW_TRACE_COUNT
-            c_prim++;
-#endif
-            int pi;
-            const rtw_prim pr = load_leaf(A.sc, tm, first, pi);
-            v3 po, pd, mt;
-            object_ray(A.sc, pr, o, d, ray_time, po, pd, mt);
-            v3 pinv = inv;
-            if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
-            float t;
+            const uint32_t first = pend >> 2, cnt = pend & 3u;
+            pend = 0u;
             bool stop = false;
-            if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gt, ng, t)) {
-                // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
-                if (t < best_t || (!shadow_phase && t == best_t && best_prim >= 0 && pi < best_prim)) {
-                    best_t = t; best_prim = pi;
-                    stop = shadow_phase;
+            for (uint32_t k = 0; k < cnt && !stop; k++) {
+#ifdef RTW_TRACE_COUNT
+                c_prim++;
+#endif
+                int pi;
+                const rtw_prim pr = load_leaf(A.sc, tm, first + k, pi);
+                v3 po, pd, mt;
+                object_ray(A.sc, pr, o, d, ray_time, po, pd, mt);
+                v3 pinv = inv;
+                if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
+                float t;
+                if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gt, ng, t)) {
+                    // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
+                    if (t < best_t || (!shadow_phase && t == best_t && best_prim >= 0 && pi < best_prim)) {
+                        best_t = t; best_prim = pi;
+                        stop = shadow_phase;
+                    }
                 }
             }
-            cur = stop ? kBvhDone : (cnt > 1u ? (((first + 1u) << 2) | (cnt - 1u)) : bvh_pop(tm, sp));
+            if (stop) cur = kBvhDone;
+            RTW_SET_ASIDE
         }
+#undef RTW_SET_ASIDE
         if (active) {
-            if (cur == kBvhDone) {
+            if (cur == kBvhDone && pend == 0u) {
                 // this ray is done
                 if (!shadow_phase) {
                     th = best_t; prim = best_prim;
@@ -1376,7 +1386,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
     v3 ldir = o, c = o;      // pending light sample: probe direction, contribution
     float ltmax = -1.f;
     // per lane: the walk
-    uint32_t cur = kBvhDone;
+    uint32_t cur = kBvhDone, pend = 0;
     int sp = 0, best_prim = -1;
     float best_t = 0.f, tmin = 0.f, wtime = 0.f;
     v3 wd = o, inv = o;
@@ -1509,16 +1519,20 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
             }
             continue;
         }
-        // ---- walk step: inner nodes while the lanes standing at one are not outnumbered, then one leaf primitive
+        // ---- walk step: inner nodes while the lanes standing at one are not outnumbered, then the primitives of the leaves
+        // put aside (a lane that comes to a leaf walks on with the next node of its stack: see k_trace_bvh)
         RTW_MARK("walk_r");
         const bool walking = busy && phase != PH_SHADE;
         const uint32_t n_walk = n_busy - n_shade;
+#define RTW_SET_ASIDE if (walking && pend == 0u && ((cur & 3u) - 1u) < 2u) { pend = cur; cur = bvh_pop(tm, sp); }
+        RTW_SET_ASIDE
         bool at_inner = walking && (cur & 3u) == 0u;
         for (;;) {
             const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
             if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_walk - n_in) break;
             if (at_inner) {
                 cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
+                RTW_SET_ASIDE
                 at_inner = (cur & 3u) == 0u;
             }
 #ifdef RTW_PHASE_TIMERS
@@ -1529,28 +1543,32 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
         st_cnt[2]++;
 #endif
         RTW_MARK("walk_s");
-        const bool at_leaf = walking && !at_inner && cur != kBvhDone;
-        if (at_leaf) {
-            const uint32_t first = cur >> 2, cnt = cur & 3u;
-            int pi;
-            const rtw_prim pr = load_leaf(A.sc, tm, first, pi);
-            v3 po, pd, mt;
-            object_ray(A.sc, pr, o, wd, wtime, po, pd, mt);
-            v3 pinv = inv;
-            if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
-            float t;
+        if (walking && pend != 0u) {
+            const uint32_t first = pend >> 2, cnt = pend & 3u;
+            pend = 0u;
             bool stop = false;
-            if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time_of(A, gk), ng, t)) {
-                // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
-                if (t < best_t || (phase == PH_RAY && t == best_t && best_prim >= 0 && pi < best_prim)) {
-                    best_t = t; best_prim = pi;
-                    stop = phase == PH_PROBE;
+            for (uint32_t k = 0; k < cnt && !stop; k++) {
+                int pi;
+                const rtw_prim pr = load_leaf(A.sc, tm, first + k, pi);
+                v3 po, pd, mt;
+                object_ray(A.sc, pr, o, wd, wtime, po, pd, mt);
+                v3 pinv = inv;
+                if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
+                float t;
+                if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time_of(A, gk), ng, t)) {
+                    // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
+                    if (t < best_t || (phase == PH_RAY && t == best_t && best_prim >= 0 && pi < best_prim)) {
+                        best_t = t; best_prim = pi;
+                        stop = phase == PH_PROBE;
+                    }
                 }
             }
-            cur = stop ? kBvhDone : (cnt > 1u ? (((first + 1u) << 2) | (cnt - 1u)) : bvh_pop(tm, sp));
+            if (stop) cur = kBvhDone;
+            RTW_SET_ASIDE
         }
+#undef RTW_SET_ASIDE
         RTW_MARK("shade_b");
-        if (walking && cur == kBvhDone) {
+        if (walking && cur == kBvhDone && pend == 0u) {
             if (phase == PH_PROBE) {
                 // traceOcclusion (closehit.cu:16-42) is back: a free path to the light adds the held contribution
                 if (best_prim < 0) L = vadd(L, c);
