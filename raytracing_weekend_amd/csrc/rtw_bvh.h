@@ -11,9 +11,14 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 #include <vector>
 
 #include "../../include/rtw.h"
+
+#ifndef RTW_LEAF_MAX
+#define RTW_LEAF_MAX 1  // primitives per leaf: 1 or 2 (count bits 3 mark "nothing": kBvhDone); measured: 1 is 5-7 % faster on scenes 1, 2, 4
+#endif
 
 namespace rtwbvh {
 
@@ -121,20 +126,24 @@ struct Q4Node {
 static_assert(sizeof(Q4Node) == 64, "Q4Node layout");
 
 // A leaf entry in tree order: what the intersection programs of spheres and rectangles read (p[0..4] of rtw_prim), so a
-// leaf visit is one 32-byte load instead of index -> primitive record; other kinds (moving spheres) keep kind = their
-// type and are fetched from the primitive table.
+// leaf visit is one 32-byte load instead of index -> primitive record. A moving sphere takes two consecutive slots:
+// centre 0 and radius, t0 (p[4]) and t1 (aux) in the first, centre 1 in the second - its intersection program
+// (geometry/movingSphere.cu:33-39 under the motion transform of ioMovingSphere.h:161-203) then needs no other load either.
+// Primitives under an instance transform keep their slot(s) and fetch the matrix (and, for other kinds, the primitive).
 struct LeafRec {
     float p[5];
     int32_t prim;
     uint32_t type_xform;  // rtw_prim_type | xform << 8
-    uint32_t pad;
+    uint32_t aux;         // moving sphere: the bits of t1
 };
 static_assert(sizeof(LeafRec) == 32, "LeafRec layout");
 
 struct Bvh {
     std::vector<Node> nodes;
     std::vector<Q4Node> q4;           // the 4-wide tree, breadth-first; q4[0] is the root
-    std::vector<LeafRec> leaves;      // leaf entries in tree order
+    std::vector<LeafRec> leaves;      // leaf slots in tree order (+ one slot of padding at the end)
+    std::vector<uint32_t> slot_of;    // leaf entry (index into prim_order) -> its first slot
+    uint32_t n_slots = 0;             // slots in use
     std::vector<int32_t> prim_order;  // leaf entries -> primitive index
     int max_depth = 0;                // of the BVH2
     int stack_need = 0;               // most entries a walk of the 4-wide tree can have on its stack (+ 1 of slack)
@@ -150,7 +159,7 @@ inline void build(std::vector<Item>& items, int lo, int hi, int node_idx, int de
     for (int i = lo; i < hi; i++) { nb.add(items[i].b); cb.add(items[i].c); }
     for (int i = 0; i < 3; i++) { out.nodes[node_idx].mn[i] = nb.mn[i]; out.nodes[node_idx].mx[i] = nb.mx[i]; }
     int n = hi - lo;
-    if (n <= 2) {
+    if (n <= RTW_LEAF_MAX) {
         out.nodes[node_idx].left_first = static_cast<uint32_t>(lo);
         out.nodes[node_idx].count = static_cast<uint32_t>(n);
         return;
@@ -277,7 +286,7 @@ inline void collapse(Bvh& out) {
                 w.lo[a] = (w.lo[a] & ~(0xffu << (8 * k))) | ((uint32_t)ql << (8 * k));
                 w.hi[a] = (w.hi[a] & ~(0xffu << (8 * k))) | ((uint32_t)qh << (8 * k));
             }
-            if (ch.count) w.ref[k] = (ch.left_first << 2) | ch.count;
+            if (ch.count) w.ref[k] = (out.slot_of[ch.left_first] << 2) | ch.count;
             else { w.ref[k] = (uint32_t)q4_of[kids[qi][k]] << 2; nd = std::max(nd, need[(size_t)q4_of[kids[qi][k]]]); }
         }
         need[qi] = (int)kids[qi].size() - 1 + nd;
@@ -312,8 +321,22 @@ inline Bvh build_bvh(const rtw_prim* prims, uint32_t n_prims, const rtw_xform* x
         for (int k = 0; k < 5; k++) lr.p[k] = pr.p[k];
         lr.prim = items[i].prim;
         lr.type_xform = (uint32_t)pr.type | ((uint32_t)pr.xform << 8);
-        out.leaves.push_back(lr);
+        out.slot_of.push_back((uint32_t)out.leaves.size());
+        if (pr.type == RTW_PRIM_MOVING_SPHERE) {  // p[0..3] centre 0, radius; p[4..6] centre 1; p[7] t0, p[8] t1 (rtw.h)
+            lr.p[4] = pr.p[7];
+            memcpy(&lr.aux, &pr.p[8], sizeof(uint32_t));
+            out.leaves.push_back(lr);
+            LeafRec l2{};
+            for (int k = 0; k < 3; k++) l2.p[k] = pr.p[4 + k];
+            l2.prim = items[i].prim;
+            l2.type_xform = lr.type_xform;
+            out.leaves.push_back(l2);
+        } else {
+            out.leaves.push_back(lr);
+        }
     }
+    out.n_slots = (uint32_t)out.leaves.size();
+    out.leaves.push_back(LeafRec{});  // a walk reads the slot after a record's first before it knows the kind
     detail::collapse(out);
     return out;
 }

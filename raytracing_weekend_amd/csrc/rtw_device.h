@@ -347,6 +347,7 @@ struct DScene {
     // noise tables staged in LDS, or -1
     int32_t n_lds_nodes, stack_depth, has_tex, noise_lds_data;
     int32_t n_lds_leaves, stack_wide;        // leaf records staged in LDS; 1 = 32-bit stack entries (references beyond 16 bits)
+    int32_t n_nodes;                         // nodes of the 4-wide tree (n_lds_nodes == n_nodes: the LDS image holds them all)
     int32_t estimator;                       // rtw_estimator of the current render (set per call, not at upload)
     float ray_tmin, probe_eps;               // 1e-6 / 5e-5 as the reference; 1e-3 for the corrected estimators
     const rtw_light* __restrict__ clights;   // RTW_EST_CORRECTED: the light list moved onto the emitting rectangles
@@ -403,6 +404,9 @@ RTW_DEV BruteRec load_rec(const DScene& sc, int i) {
     r.e = __uint_as_float(q[4]); r.prim = (int)q[5]; r.pad0 = 0; r.pad1 = 0;
     return r;
 }
+#ifndef RTW_LEAF_MAX
+#define RTW_LEAF_MAX 1  // primitives per leaf of the tree (rtw_bvh.h builds to the same constant)
+#endif
 static constexpr uint32_t kBvhDone = 0xffffffffu;  // a reference with count bits = 3: neither an inner node nor a leaf that exists
 // Per-thread traversal memory: this thread's column of the LDS stack, the block's LDS copy of the top of the tree and
 // of the first leaf records. Stack entries are 16 bits wide whenever every reference of the tree fits (the LDS the
@@ -422,10 +426,12 @@ struct TravMem {
 RTW_DEV TravMem trav_mem(const DScene& sc, uint32_t* lds, uint32_t block, uint32_t tid) {
     TravMem tm;
     tm.wide = sc.stack_wide != 0;
-    // row 0 of a column holds "nothing left" for good (a pop of the empty stack reads it), the stack proper starts at row 1
-    if (tm.wide) lds[tid] = kBvhDone; else ((uint16_t*)lds)[tid] = 0xffffu;
-    tm.stack16 = (uint16_t*)lds + block + tid;
-    tm.stack32 = lds + block + tid;
+    // rows 0 and 1 of a column hold "nothing left" for good (a pop of the empty stack reads row 1; bvh_step16 looks two
+    // entries down), the stack proper starts at row 2
+    if (tm.wide) { lds[tid] = kBvhDone; lds[block + tid] = kBvhDone; }
+    else { ((uint16_t*)lds)[tid] = 0xffffu; ((uint16_t*)lds)[block + tid] = 0xffffu; }
+    tm.stack16 = (uint16_t*)lds + 2u * block + tid;
+    tm.stack32 = lds + 2u * block + tid;
     tm.stride = block;
     const uint32_t stack_words = tm.wide ? (uint32_t)sc.stack_depth * block : ((uint32_t)sc.stack_depth * block + 1u) / 2u;
     u32x4* cache = (u32x4*)(lds + ((stack_words + 3u) & ~3u));
@@ -646,24 +652,136 @@ RTW_DEV uint32_t bvh_inner_step(const DScene& sc, const TravMem& tm, const v3 o,
     return none ? top : slot == 0u ? q3.x : slot == 1u ? q3.y : slot == 2u ? q3.z : q3.w;
 }
 
-// Leaf record `k` of the tree as a primitive record: spheres and rectangles come whole from the 32-byte record (their
-// intersection programs read p[0..4] only), other kinds from the primitive table.
-RTW_DEV rtw_prim load_leaf(const DScene& sc, const TravMem& tm, uint32_t k, int& prim) {
-    u32x4 a, b;
-    if (k < tm.n_leaves) { a = tm.leaves[2u * k]; b = tm.leaves[2u * k + 1u]; }
-    else {
+// The same step for trees whose references fit 16 bits (every scene of a few thousand primitives), written without a
+// divergent branch: the slot of the nearest child is picked with selects, the stack top and the entry under it are read
+// together, and a leaf that comes up while the lane has none put aside goes to `pend` at once (the lane walks on with the
+// next entry: see k_trace_bvh). cur must be an inner reference; on return cur is the next reference of any kind, or
+// kBvhDone. ALL_LDS: the workgroup's LDS image holds every node (no global fetch, so no vmcnt wait in the loop).
+template <bool ALL_LDS>
+RTW_DEV void bvh_step16(const DScene& sc, const TravMem& tm, const v3 o, const v3 inv, float tmin, float best_t, uint32_t& cur, uint32_t& pend, int& sp) {
+    const uint32_t i = cur >> 2;
+    u32x4 q0, q1, q2, q3;
+    if (ALL_LDS || i < tm.n_nodes) {
+        const u32x4* q = tm.nodes + 4u * i;
+        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+    } else {
+        const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + 4u * i);
+        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+    }
+    const float ix = __builtin_amdgcn_fmed3f(inv.x, -1.0e18f, 1.0e18f), iy = __builtin_amdgcn_fmed3f(inv.y, -1.0e18f, 1.0e18f),
+                iz = __builtin_amdgcn_fmed3f(inv.z, -1.0e18f, 1.0e18f);
+    const float ax = (__uint_as_float(q0.x) - o.x) * ix, ay = (__uint_as_float(q0.y) - o.y) * iy, az = (__uint_as_float(q0.z) - o.z) * iz;
+    const float bx = __uint_as_float(q0.w) * ix, by = __uint_as_float(q2.z) * iy, bz = __uint_as_float(q2.w) * iz;
+    const uint32_t nx = ix < 0.0f ? q1.w : q1.x, fx = ix < 0.0f ? q1.x : q1.w;
+    const uint32_t ny = iy < 0.0f ? q2.x : q1.y, fy = iy < 0.0f ? q1.y : q2.x;
+    const uint32_t nz = iz < 0.0f ? q2.y : q1.z, fz = iz < 0.0f ? q1.z : q2.y;
+    uint32_t key[4];
+    // an unused slot holds an inverted box (lo = 255, hi = 0 on every axis): its near plane lies 255 grid steps beyond its
+    // far plane, so it never passes tn <= tf and needs no test of its own
+#define RTW_Q4_CHILD(C_)                                                                                                         \
+    {                                                                                                                            \
+        const float tnx = fma_((float)((nx >> (8 * C_)) & 0xffu), bx, ax), tfx = fma_((float)((fx >> (8 * C_)) & 0xffu), bx, ax); \
+        const float tny = fma_((float)((ny >> (8 * C_)) & 0xffu), by, ay), tfy = fma_((float)((fy >> (8 * C_)) & 0xffu), by, ay); \
+        const float tnz = fma_((float)((nz >> (8 * C_)) & 0xffu), bz, az), tfz = fma_((float)((fz >> (8 * C_)) & 0xffu), bz, az); \
+        const float tn = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, tmin));                                \
+        const float tf = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, best_t));                              \
+        key[C_] = tn <= tf ? ((__float_as_uint(tn) & ~3u) | (uint32_t)C_) : 0xffffffffu;                                        \
+    }
+    RTW_Q4_CHILD(0) RTW_Q4_CHILD(1) RTW_Q4_CHILD(2) RTW_Q4_CHILD(3)
+#undef RTW_Q4_CHILD
+    const uint32_t kmin = min(min(key[0], key[1]), min(key[2], key[3]));
+    // (a slot that is not hit has the key ~0, which is kmin only when nothing is hit: `!= kmin` alone would push it then)
+    const bool p0 = key[0] != 0xffffffffu && key[0] != kmin, p1 = key[1] != 0xffffffffu && key[1] != kmin,
+               p2 = key[2] != 0xffffffffu && key[2] != kmin, p3 = key[3] != 0xffffffffu && key[3] != kmin;
+    char* b = (char*)tm.stack16;
+    const int st = (int)(tm.stride * 2u);
+    *(uint16_t*)(b + sp) = (uint16_t)q3.x; sp += p0 ? st : 0;
+    *(uint16_t*)(b + sp) = (uint16_t)q3.y; sp += p1 ? st : 0;
+    *(uint16_t*)(b + sp) = (uint16_t)q3.z; sp += p2 ? st : 0;
+    *(uint16_t*)(b + sp) = (uint16_t)q3.w; sp += p3 ? st : 0;
+    const uint32_t e1 = (uint32_t)(int32_t)*(const int16_t*)(b + (sp - st));       // the top of the stack
+    const uint32_t e2 = (uint32_t)(int32_t)*(const int16_t*)(b + (sp - 2 * st));   // and what lies under it
+    const bool none = kmin == 0xffffffffu;
+    const uint32_t r01 = (kmin & 1u) ? q3.y : q3.x, r23 = (kmin & 1u) ? q3.w : q3.z;
+    const uint32_t sel = (kmin & 2u) ? r23 : r01;
+    const uint32_t c1 = none ? e1 : sel;     // the next reference
+    const uint32_t c2 = none ? e2 : e1;      // the one after it, should c1 be a leaf that is put aside
+    sp -= none ? st : 0;
+    const bool aside = pend == 0u && ((c1 & 3u) - 1u) < 2u;
+    pend = aside ? c1 : pend;
+    cur = aside ? c2 : c1;
+    sp -= aside ? st : 0;
+}
+
+RTW_DEV bool uses_inv(int type) { return type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_VOLUME_BOX; }
+RTW_DEV v3 recip3(v3 d) { return V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
+// The walks that test surfaces only hand this to prim_test (volume kinds, which draw, never reach a tree)
+struct NoDraw {
+    RTW_DEV float randf1() { return 0.0f; }
+    RTW_DEV float next1() { return 0.0f; }
+};
+
+// One leaf record (slot k of the leaf table) against a ray, for every walk of the tree (surfaces only: no intersection
+// program that reaches a tree draws random numbers). Untransformed spheres, moving spheres and rectangles - most of any
+// scene - are tested straight from their slots, the rectangle's axes picked with selects; primitives under an instance
+// transform take the general route through object_ray / prim_test. The arithmetic per kind is prim_test's, so the hit
+// distances are the same bits. inv = recip3(d), computed once per ray. next = the slot after this record.
+RTW_DEV bool leaf_test(const DScene& sc, const TravMem& tm, uint32_t k, const v3 o, const v3 d, const v3 inv, float tmin, float ray_time,
+                       float gather_time, float& t, int& prim, uint32_t& next) {
+    u32x4 a, b, c;
+    c = u32x4{0u, 0u, 0u, 0u};
+    // (the slot after the record's first is only a moving sphere's second centre; scenes without one never fetch it)
+    if (k + 1u < tm.n_leaves) {
+        a = tm.leaves[2u * k]; b = tm.leaves[2u * k + 1u];
+        if (sc.has_motion) c = tm.leaves[2u * k + 2u];
+    } else {
         const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.leaves + 2u * k);
         a = q[0]; b = q[1];
+        if (sc.has_motion) c = q[2];
     }
     prim = (int)b.y;
-    const int type = (int)(b.z & 0xffu);
-    if (type != RTW_PRIM_SPHERE && !(type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_RECT_Z)) return load_prim(sc, prim);
-    rtw_prim r;
-    r.type = type; r.material = 0; r.xform = (int)(b.z >> 8); r.flip = 0;
-    r.p[0] = __uint_as_float(a.x); r.p[1] = __uint_as_float(a.y); r.p[2] = __uint_as_float(a.z); r.p[3] = __uint_as_float(a.w);
-    r.p[4] = __uint_as_float(b.x);
-    for (int j = 5; j < 12; j++) r.p[j] = 0.0f;
-    return r;
+    const uint32_t tx = b.z;  // type | xform << 8
+    next = k + ((tx & 0xffu) == (uint32_t)RTW_PRIM_MOVING_SPHERE ? 2u : 1u);
+    const v3 c0 = V(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
+    if (tx == (uint32_t)RTW_PRIM_SPHERE)  // geometry/sphere.cu:52-60,93-95
+        return sphere_roots(o, d, c0, __uint_as_float(a.w), tmin, RTW_FLT_MAX, t);
+    if (tx == (uint32_t)RTW_PRIM_MOVING_SPHERE) {
+        // the matrix-motion transform translate(lerp(C0, C1, rayTime)) (geometry/ioMovingSphere.h:161-203) and, on top
+        // of it, the program's own centre at the gather time (geometry/movingSphere.cu:33-39): object_ray + prim_test
+        const v3 dc = vsub(V(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)), c0);
+        const float t0 = __uint_as_float(b.x), t1 = __uint_as_float(b.w);
+        const v3 oo = vsub(o, vfma(dc, ray_time, c0));
+        const v3 ctr = t0 == t1 ? c0 : vfma(dc, (gather_time - t0) / (t1 - t0), c0);
+        return sphere_roots(oo, d, ctr, __uint_as_float(a.w), tmin, RTW_FLT_MAX, t);
+    }
+    if (tx - (uint32_t)RTW_PRIM_RECT_X <= (uint32_t)(RTW_PRIM_RECT_Z - RTW_PRIM_RECT_X)) {
+        // shaders/aarectx.cu:8-22, aarecty.cu:8-22, aarectz.cu:9-23
+        const bool isx = tx == (uint32_t)RTW_PRIM_RECT_X, isz = tx == (uint32_t)RTW_PRIM_RECT_Z;
+        const float ok = isx ? o.x : isz ? o.z : o.y, ik = isx ? inv.x : isz ? inv.z : inv.y;
+        const float oa = isx ? o.y : o.x, da = isx ? d.y : d.x;
+        const float ob = isz ? o.y : o.z, db = isz ? d.y : d.z;
+        const float tt = (__uint_as_float(b.x) - ok) * ik;
+        const float aa = fma_(tt, da, oa);
+        const float bb = fma_(tt, db, ob);
+        t = tt;
+        return (tt >= tmin) & (tt < RTW_FLT_MAX) & (aa >= __uint_as_float(a.x)) & (aa <= __uint_as_float(a.y)) & (bb >= __uint_as_float(a.z)) &
+               (bb <= __uint_as_float(a.w));
+    }
+    const int type = (int)(tx & 0xffu);
+    rtw_prim pr;
+    if (type != RTW_PRIM_SPHERE && !(type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_RECT_Z)) pr = load_prim(sc, prim);
+    else {
+        pr.type = type; pr.material = 0; pr.xform = (int)(tx >> 8); pr.flip = 0;
+        pr.p[0] = __uint_as_float(a.x); pr.p[1] = __uint_as_float(a.y); pr.p[2] = __uint_as_float(a.z); pr.p[3] = __uint_as_float(a.w);
+        pr.p[4] = __uint_as_float(b.x);
+        for (int j = 5; j < 12; j++) pr.p[j] = 0.0f;
+    }
+    v3 po, pd, mt;
+    object_ray(sc, pr, o, d, ray_time, po, pd, mt);
+    v3 pinv = inv;
+    if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
+    NoDraw ng;
+    return prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time, ng, t);
 }
 
 // Conservative: false only when the ray certainly stays outside the scene bounds (NaNs from 0 * inf answer "may hit").
@@ -680,8 +798,6 @@ RTW_DEV bool may_hit_scene(const DScene& sc, const v3 o, const v3 d) {
     return any_nan || !(tnear > tfar * 1.001f);
 }
 
-RTW_DEV bool uses_inv(int type) { return type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_VOLUME_BOX; }
-RTW_DEV v3 recip3(v3 d) { return V(1.0f / d.x, 1.0f / d.y, 1.0f / d.z); }
 
 // The volume primitives' share of a traversal: tested first, in index order, each against the interval the earlier
 // ones left (their intersection programs draw random numbers: geometry/volumeBox.cu:79, volumeSphere.cu:93).
@@ -922,16 +1038,12 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
     for (;;) {
         while ((cur & 3u) == 0u) cur = bvh_inner_step(sc, tm, o, inv, tmin, best_t, cur, sp);
         if (cur == kBvhDone) break;
-        const uint32_t first = cur >> 2, cnt = cur & 3u;
+        uint32_t slot = cur >> 2;
+        const uint32_t cnt = cur & 3u;
         for (uint32_t k = 0; k < cnt; k++) {
             int pi;
-            const rtw_prim pr = load_leaf(sc, tm, first + k, pi);
-            v3 po, pd, mt;
-            object_ray(sc, pr, o, d, ray_time, po, pd, mt);
-            v3 pinv = inv;
-            if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
             float t;
-            if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time, g, t)) { RTW_ACCEPT(t, pi) }
+            if (leaf_test(sc, tm, slot, o, d, inv, tmin, ray_time, gather_time, t, pi, slot)) { RTW_ACCEPT(t, pi) }
         }
         cur = bvh_pop(tm, sp);
         if (cur == kBvhDone) break;

@@ -289,6 +289,15 @@ size_t tree_lds_layout(size_t n_nodes_all, size_t n_leaves_all, int stack_depth,
     return stack_bytes + (size_t)n_nodes * sizeof(rtwbvh::Q4Node) + (size_t)n_leaves * sizeof(rtwbvh::LeafRec);
 }
 
+// k_trace_bvh's instantiation for a workgroup size and a tree (mode: see the kernel)
+typedef void (*TraceBvhKernel)(const KArgs);
+int trace_bvh_mode(const DScene& sc) { return sc.stack_wide ? 0 : sc.n_lds_nodes >= sc.n_nodes ? 2 : 1; }
+TraceBvhKernel trace_bvh_kernel(int block, int mode) {
+#define RTW_TB(B_) (mode == 0 ? k_trace_bvh<B_, 0> : mode == 1 ? k_trace_bvh<B_, 1> : k_trace_bvh<B_, 2>)
+    return block == 1024 ? RTW_TB(1024) : block == 512 ? RTW_TB(512) : RTW_TB(256);
+#undef RTW_TB
+}
+
 enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE, LK_PATH = RTW_K_PATH, LK_PATH_TREE = RTW_K_COUNT };
 void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s, int block = kBlock) {
     const bool lcg = rng_kind == RTW_RNG_TEA_LCG;
@@ -305,11 +314,7 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
     case LK_FIRST: RTW_LAUNCH_SHADING(k_first, lds); break;
     case LK_SHADE: RTW_LAUNCH_SHADING(k_shade, 0); break;
     case LK_TRACE:
-        if (a.sc.use_bvh) {
-            if (block == 1024) hipLaunchKernelGGL((k_trace_bvh<1024>), dim3(grid), dim3(1024), lds, s, a);
-            else if (block == 512) hipLaunchKernelGGL((k_trace_bvh<512>), dim3(grid), dim3(512), lds, s, a);
-            else hipLaunchKernelGGL((k_trace_bvh<256>), dim3(grid), dim3(256), lds, s, a);
-        }
+        if (a.sc.use_bvh) hipLaunchKernelGGL(trace_bvh_kernel(block, trace_bvh_mode(a.sc)), dim3(grid), dim3(block), lds, s, a);
         else if (a.sc.n_generic == 0) hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(kBlock), lds, s, a);
         else hipLaunchKernelGGL((k_trace<false>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
@@ -701,16 +706,17 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.cam_type = h.camera_type;
     // LDS per block: the traversal stacks (16-bit entries when every reference fits), then as many leading (breadth-first)
     // tree nodes and, behind them, leaf records as fit the budget
-    c->stack_depth = use_bvh ? bvh.stack_need + 1 : 0;  // + the row under the stack that ends a walk
+    c->stack_depth = use_bvh ? bvh.stack_need + 2 : 0;  // + the two rows under the stack that end a walk
     sc.stack_depth = c->stack_depth;
     sc.n_lds_nodes = 0; sc.n_lds_leaves = 0; sc.stack_wide = 0;
     c->lds_bytes = 0;
     if (use_bvh) {
-        sc.stack_wide = (std::max(bvh.q4.size(), bvh.leaves.size()) << 2) >= 0x7ff0u ? 1 : 0;  // 16-bit entries are read sign-extended
-        c->n_tree_nodes = bvh.q4.size(); c->n_tree_leaves = bvh.leaves.size();
+        sc.stack_wide = (std::max(bvh.q4.size(), (size_t)bvh.n_slots) << 2) >= 0x7ff0u ? 1 : 0;  // 16-bit entries are read sign-extended
+        c->n_tree_nodes = bvh.q4.size(); c->n_tree_leaves = bvh.n_slots;
+        sc.n_nodes = (int32_t)bvh.q4.size();
         c->lds_bytes = tree_lds_layout(c->n_tree_nodes, c->n_tree_leaves, c->stack_depth, sc.stack_wide != 0, kBlock, tune.lds_kb * 1024, sc.n_lds_nodes, sc.n_lds_leaves);
         if (tune.verbose) fprintf(stderr, "[rtw] tree: %zu nodes, %zu leaf records, stack %d x %d bit; LDS %zu B: %d nodes, %d leaf records\n",
-                                  bvh.q4.size(), bvh.leaves.size(), c->stack_depth, sc.stack_wide ? 32 : 16, c->lds_bytes, sc.n_lds_nodes, sc.n_lds_leaves);
+                                  bvh.q4.size(), (size_t)bvh.n_slots, c->stack_depth, sc.stack_wide ? 32 : 16, c->lds_bytes, sc.n_lds_nodes, sc.n_lds_leaves);
     }
     c->sc = sc;
     c->has_scene = true;
@@ -945,7 +951,9 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         const size_t by_waves = std::max<size_t>(1, (size_t)(4 * tune.trace_waves) / ((size_t)trace_block / 64));
         trace_grid = (int)((size_t)c->n_cu * std::min(by_lds, by_waves));
         if (trace_lds > 48 * 1024) {  // beyond the default dynamic-LDS limit of a launch
-            const void* f = trace_block == 1024 ? (const void*)k_trace_bvh<1024> : trace_block == 512 ? (const void*)k_trace_bvh<512> : (const void*)k_trace_bvh<256>;
+            DScene ts = c->sc;
+            ts.n_lds_nodes = trace_nodes;
+            const void* f = (const void*)trace_bvh_kernel(trace_block, trace_bvh_mode(ts));
             HIP_TRY(c, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)trace_lds));
         }
     }
@@ -1095,12 +1103,16 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
 #endif
 #ifdef RTW_TRACE_COUNT
     {
-        unsigned long long w[2];
+        unsigned long long w[6];
         HIP_TRY_C(hipMemcpy(w, c->d_stats + kStatRows * 8, sizeof w, hipMemcpyDeviceToHost));
         const double rays = (double)hs[2 + RTW_K_TRACE];
         fprintf(stderr, "[rtw] k_trace_bvh: rays %.4g; per ray: node visits %.2f, primitive tests %.2f; wave steps per 64 rays: inner %.2f (lanes busy %.2f), leaf %.2f (lanes busy %.2f), outer %.2f\n",
                 rays, (double)hs[6] / rays, (double)hs[7] / rays, (double)w[0] * 64.0 / rays, (double)hs[6] / ((double)w[0] * 64.0), (double)w[1] * 64.0 / rays,
                 (double)hs[7] / ((double)w[1] * 64.0), (double)hs[2 + RTW_K_BOUNCE] * 64.0 / rays);
+        const double tt = (double)(w[2] + w[3] + w[4] + w[5]);
+        fprintf(stderr, "[rtw] k_trace_bvh wave-cycles: refill %.1f%% inner %.1f%% leaf %.1f%% finish %.1f%% (%.0f per 64 rays; per inner wave step %.0f, per leaf wave step %.0f)\n",
+                100.0 * (double)w[2] / tt, 100.0 * (double)w[3] / tt, 100.0 * (double)w[4] / tt, 100.0 * (double)w[5] / tt, tt * 64.0 / rays,
+                (double)w[3] / (double)w[0], (double)w[4] / (double)w[1]);
     }
 #endif
     if (stats) {

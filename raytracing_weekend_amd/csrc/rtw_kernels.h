@@ -727,7 +727,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
 // DUAL = 1: small static scenes, both rays share one walk over the scalar-cache candidate lists (64 VGPRs, 8 waves);
 // DUAL = 0: BVH / moving-sphere scenes, one traversal per ray (the 64-byte node records want the larger budget).
 #ifndef RTW_TRACE_BVH_WAVES
-#define RTW_TRACE_BVH_WAVES 4
+#define RTW_TRACE_BVH_WAVES 6
 #endif
 template <bool DUAL>
 __global__ void __launch_bounds__(kBlock, DUAL ? 8 : RTW_TRACE_BVH_WAVES) k_trace(const KArgs A) {
@@ -766,7 +766,10 @@ __global__ void __launch_bounds__(kBlock, DUAL ? 8 : RTW_TRACE_BVH_WAVES) k_trac
 #ifndef RTW_LEAF_BIAS
 #define RTW_LEAF_BIAS 1
 #endif
-template <int BLOCK>
+// MODE 0: 32-bit stack entries (trees beyond 8 K references; the step with branches); 1: 16-bit entries, nodes beyond the
+// LDS image come from global memory; 2: 16-bit entries and every node in LDS (the walk loop then holds no global load,
+// so the stores of finished rays and the loads of a refill are never waited for inside it)
+template <int BLOCK, int MODE>
 __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED_T(BLOCK)
@@ -792,11 +795,17 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
     const uint32_t root = A.sc.n_tree > 0 ? 0u : kBvhDone;
 #ifdef RTW_TRACE_COUNT
     uint32_t c_inner = 0, c_prim = 0, c_outer = 0, c_winner = 0, c_wleaf = 0;
+    // wave cycles by part of the loop: 0 refill, 1 inner steps, 2 leaf step, 3 finished rays
+    unsigned long long tc[4] = {0, 0, 0, 0}, tc_t0 = __builtin_amdgcn_s_memtime();
+#define RTW_TC(I_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tc[I_] += now_ - tc_t0; tc_t0 = now_; }
+#else
+#define RTW_TC(I_)
 #endif
     for (;;) {
 #ifdef RTW_TRACE_COUNT
         c_outer++;
 #endif
+        RTW_TC(3)
         const unsigned long long idle = __ballot(!active);
         const uint32_t n_idle = (uint32_t)__popcll(idle);
         if (n_idle == 64u || (n_idle >= (uint32_t)RTW_REFILL_IDLE && !exhausted)) {
@@ -847,6 +856,7 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
         // until it is the majority. A lane that comes to a leaf puts it aside (pend) and walks on with the next
         // node of its stack: it only has to wait at its second leaf. The nodes it visits meanwhile are culled
         // against a best_t that has not seen the leaf yet - a few more visits, never a different result.
+        RTW_TC(0)
         const uint32_t n_act = (uint32_t)__popcll(__ballot(active));
 #define RTW_SET_ASIDE if (active && pend == 0u && ((cur & 3u) - 1u) < 2u) { pend = cur; cur = bvh_pop(tm, sp); }
         RTW_SET_ASIDE
@@ -855,8 +865,12 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
             const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
             if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_act - n_in) break;
             if (at_inner) {
-                cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
-                RTW_SET_ASIDE
+                if (MODE == 0) {
+                    cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
+                    RTW_SET_ASIDE
+                } else {
+                    bvh_step16<MODE == 2>(A.sc, tm, o, inv, tmin, best_t, cur, pend, sp);
+                }
                 at_inner = (cur & 3u) == 0u;
 #ifdef RTW_TRACE_COUNT
                 c_inner++;
@@ -866,30 +880,30 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
             c_winner++;
 #endif
         }
+        RTW_TC(1)
         const bool at_leaf = active && pend != 0u;
 #ifdef RTW_TRACE_COUNT
         if (__ballot(at_leaf) != 0ull) c_wleaf++;
 #endif
         if (at_leaf) {
-            const uint32_t first = pend >> 2, cnt = pend & 3u;
+            uint32_t lslot = pend >> 2;
+            const uint32_t cnt = pend & 3u;
             pend = 0u;
             bool stop = false;
-            for (uint32_t k = 0; k < cnt && !stop; k++) {
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)RTW_LEAF_MAX; k++) {
+                if (k < cnt && !stop) {
 #ifdef RTW_TRACE_COUNT
-                c_prim++;
+                    c_prim++;
 #endif
-                int pi;
-                const rtw_prim pr = load_leaf(A.sc, tm, first + k, pi);
-                v3 po, pd, mt;
-                object_ray(A.sc, pr, o, d, ray_time, po, pd, mt);
-                v3 pinv = inv;
-                if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
-                float t;
-                if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gt, ng, t)) {
-                    // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
-                    if (t < best_t || (!shadow_phase && t == best_t && best_prim >= 0 && pi < best_prim)) {
-                        best_t = t; best_prim = pi;
-                        stop = shadow_phase;
+                    int pi;
+                    float t;
+                    if (leaf_test(A.sc, tm, lslot, o, d, inv, tmin, ray_time, gt, t, pi, lslot)) {
+                        // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
+                        if (t < best_t || (!shadow_phase && t == best_t && best_prim >= 0 && pi < best_prim)) {
+                            best_t = t; best_prim = pi;
+                            stop = shadow_phase;
+                        }
                     }
                 }
             }
@@ -897,6 +911,7 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
             RTW_SET_ASIDE
         }
 #undef RTW_SET_ASIDE
+        RTW_TC(2)
         if (active) {
             if (cur == kBvhDone && pend == 0u) {
                 // this ray is done
@@ -920,8 +935,11 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
     }
 #ifdef RTW_TRACE_COUNT
     for (int off = 32; off > 0; off >>= 1) { c_inner += __shfl_down(c_inner, off); c_prim += __shfl_down(c_prim, off); }
+    RTW_TC(3)
+    if ((tid & 63u) == 0) for (int q = 0; q < 4; q++) atomicAdd(&A.stats[kStatRows * 8 + 2 + q], tc[q]);
     if ((tid & 63u) == 0) { atomicAdd(&A.stats[kStatRows * 8 + 0], (unsigned long long)c_winner); atomicAdd(&A.stats[kStatRows * 8 + 1], (unsigned long long)c_wleaf); atomicAdd(&A.stats[6], (unsigned long long)c_inner); atomicAdd(&A.stats[7], (unsigned long long)c_prim); atomicAdd(&A.stats[2 + RTW_K_BOUNCE], (unsigned long long)c_outer); }
 #endif
+#undef RTW_TC
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
     if ((tid & 63u) == 0 && n_rays) atomicAdd(&stat_row(A)[2 + RTW_K_TRACE], (unsigned long long)n_rays);
 }
@@ -1544,22 +1562,21 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
 #endif
         RTW_MARK("walk_s");
         if (walking && pend != 0u) {
-            const uint32_t first = pend >> 2, cnt = pend & 3u;
+            uint32_t lslot = pend >> 2;
+            const uint32_t cnt = pend & 3u;
             pend = 0u;
             bool stop = false;
-            for (uint32_t k = 0; k < cnt && !stop; k++) {
-                int pi;
-                const rtw_prim pr = load_leaf(A.sc, tm, first + k, pi);
-                v3 po, pd, mt;
-                object_ray(A.sc, pr, o, wd, wtime, po, pd, mt);
-                v3 pinv = inv;
-                if (pr.xform != 0 && uses_inv(pr.type)) pinv = recip3(pd);
-                float t;
-                if (prim_test(pr, po, pd, pinv, tmin, RTW_FLT_MAX, gather_time_of(A, gk), ng, t)) {
-                    // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
-                    if (t < best_t || (phase == PH_RAY && t == best_t && best_prim >= 0 && pi < best_prim)) {
-                        best_t = t; best_prim = pi;
-                        stop = phase == PH_PROBE;
+#pragma unroll
+            for (uint32_t k = 0; k < (uint32_t)RTW_LEAF_MAX; k++) {
+                if (k < cnt && !stop) {
+                    int pi;
+                    float t;
+                    if (leaf_test(A.sc, tm, lslot, o, wd, inv, tmin, wtime, gather_time_of(A, gk), t, pi, lslot)) {
+                        // same acceptance rule as traverse<>: closest, ties to the lowest primitive index; any hit ends a probe
+                        if (t < best_t || (phase == PH_RAY && t == best_t && best_prim >= 0 && pi < best_prim)) {
+                            best_t = t; best_prim = pi;
+                            stop = phase == PH_PROBE;
+                        }
                     }
                 }
             }
