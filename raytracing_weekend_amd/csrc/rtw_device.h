@@ -657,7 +657,7 @@ RTW_DEV uint32_t bvh_inner_step(const DScene& sc, const TravMem& tm, const v3 o,
 // together, and a leaf that comes up while the lane has none put aside goes to `pend` at once (the lane walks on with the
 // next entry: see k_trace_bvh). cur must be an inner reference; on return cur is the next reference of any kind, or
 // kBvhDone. ALL_LDS: the workgroup's LDS image holds every node (no global fetch, so no vmcnt wait in the loop).
-template <bool ALL_LDS>
+template <bool ALL_LDS, bool ASIDE = true>
 RTW_DEV void bvh_step16(const DScene& sc, const TravMem& tm, const v3 o, const v3 inv, float tmin, float best_t, uint32_t& cur, uint32_t& pend, int& sp) {
     const uint32_t i = cur >> 2;
     u32x4 q0, q1, q2, q3;
@@ -700,17 +700,22 @@ RTW_DEV void bvh_step16(const DScene& sc, const TravMem& tm, const v3 o, const v
     *(uint16_t*)(b + sp) = (uint16_t)q3.z; sp += p2 ? st : 0;
     *(uint16_t*)(b + sp) = (uint16_t)q3.w; sp += p3 ? st : 0;
     const uint32_t e1 = (uint32_t)(int32_t)*(const int16_t*)(b + (sp - st));       // the top of the stack
-    const uint32_t e2 = (uint32_t)(int32_t)*(const int16_t*)(b + (sp - 2 * st));   // and what lies under it
     const bool none = kmin == 0xffffffffu;
     const uint32_t r01 = (kmin & 1u) ? q3.y : q3.x, r23 = (kmin & 1u) ? q3.w : q3.z;
     const uint32_t sel = (kmin & 2u) ? r23 : r01;
     const uint32_t c1 = none ? e1 : sel;     // the next reference
-    const uint32_t c2 = none ? e2 : e1;      // the one after it, should c1 be a leaf that is put aside
-    sp -= none ? st : 0;
-    const bool aside = pend == 0u && ((c1 & 3u) - 1u) < 2u;
-    pend = aside ? c1 : pend;
-    cur = aside ? c2 : c1;
-    sp -= aside ? st : 0;
+    if (ASIDE) {
+        const uint32_t e2 = (uint32_t)(int32_t)*(const int16_t*)(b + (sp - 2 * st));   // what lies under the top
+        const uint32_t c2 = none ? e2 : e1;  // the reference after c1, should c1 be a leaf that is put aside
+        sp -= none ? st : 0;
+        const bool aside = pend == 0u && ((c1 & 3u) - 1u) < 2u;
+        pend = aside ? c1 : pend;
+        cur = aside ? c2 : c1;
+        sp -= aside ? st : 0;
+    } else {  // (walks that test a leaf as soon as it comes up: traverse<>)
+        sp -= none ? st : 0;
+        cur = c1;
+    }
 }
 
 RTW_DEV bool uses_inv(int type) { return type >= RTW_PRIM_RECT_X && type <= RTW_PRIM_VOLUME_BOX; }
@@ -1036,7 +1041,8 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
     int sp = 0;
     uint32_t cur = 0;
     for (;;) {
-        while ((cur & 3u) == 0u) cur = bvh_inner_step(sc, tm, o, inv, tmin, best_t, cur, sp);
+        if (tm.wide) { while ((cur & 3u) == 0u) cur = bvh_inner_step(sc, tm, o, inv, tmin, best_t, cur, sp); }
+        else { uint32_t none_aside = 0u; while ((cur & 3u) == 0u) bvh_step16<false, false>(sc, tm, o, inv, tmin, best_t, cur, none_aside, sp); }
         if (cur == kBvhDone) break;
         uint32_t slot = cur >> 2;
         const uint32_t cnt = cur & 3u;

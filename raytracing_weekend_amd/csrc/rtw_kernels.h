@@ -1549,8 +1549,12 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
             const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
             if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_walk - n_in) break;
             if (at_inner) {
-                cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
-                RTW_SET_ASIDE
+                if (tm.wide) {
+                    cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
+                    RTW_SET_ASIDE
+                } else {
+                    bvh_step16<false>(A.sc, tm, o, inv, tmin, best_t, cur, pend, sp);
+                }
                 at_inner = (cur & 3u) == 0u;
             }
 #ifdef RTW_PHASE_TIMERS
