@@ -208,7 +208,9 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_BRUTE_MAX   largest primitive count walked with the scalar-cache brute lists (default 24; 0 forces the BVH)
 //   RTW_LDS_KB      dynamic LDS per workgroup for traversal stacks + staged tree nodes (default 16)
 //   RTW_TAIL_GROUP  bounces per launch of the first tail group (default 2; groups grow by half every second launch)
-//   RTW_STAGGER     size of the second lane's first batch in percent of a full batch (default 50; 0 = no offset)
+//   RTW_STAGGER     how far the second lane starts behind the first, in percent of a batch (its first batch is cut short by that
+//                   much; 0 = no offset). Default: 50 for the candidate-list scenes under RTW_PATH=0, 0 for tree scenes (there the
+//                   extra batch costs more than the offset gains: scenes 1, 2, 4 +1-4 % at 512+ spp, +6-13 % at 128-256 spp)
 //   RTW_PATH        1 (default): scenes walked with the brute lists render through k_path (paths in registers, in-wave
 //                   regeneration); 0: always the wavefront pipeline
 //   RTW_PATH_TREE   1: tree scenes render through k_path_tree (k_path's idea with a per-lane walk state machine and a vote on the
@@ -231,7 +233,7 @@ struct Tuning {
     int trace_block = 256;       // threads per workgroup of k_trace_bvh (256, 512, 1024)
     size_t trace_lds_kb = 16;    // its LDS budget: stacks + tree nodes + leaf records
     int trace_waves = 6;         // waves per SIMD it is launched for
-    int stagger_pct = 50;
+    int stagger_pct = -1;  // -1 = automatic
     int tail_group = 2;
     int path = 1;
     int path_tree = 0;
@@ -715,7 +717,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         c->n_tree_nodes = bvh.q4.size(); c->n_tree_leaves = bvh.n_slots;
         sc.n_nodes = (int32_t)bvh.q4.size();
         c->lds_bytes = tree_lds_layout(c->n_tree_nodes, c->n_tree_leaves, c->stack_depth, sc.stack_wide != 0, kBlock, tune.lds_kb * 1024, sc.n_lds_nodes, sc.n_lds_leaves);
-        if (tune.verbose) fprintf(stderr, "[rtw] tree: %zu nodes, %zu leaf records, stack %d x %d bit; LDS %zu B: %d nodes, %d leaf records\n",
+        if (tune.verbose) fprintf(stderr, "[rtw] tree (SAH %d, expected node visits %.3f): %zu nodes, %zu leaf records, stack %d x %d bit; LDS %zu B: %d nodes, %d leaf records\n", bvh.bins, bvh.cost,
                                   bvh.q4.size(), (size_t)bvh.n_slots, c->stack_depth, sc.stack_wide ? 32 : 16, c->lds_bytes, sc.n_lds_nodes, sc.n_lds_leaves);
     }
     c->sc = sc;
@@ -1009,7 +1011,7 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         // The second lane's first batch is cut short so that the lanes run half a batch apart: one lane's bandwidth-bound
         // k_shade launches then meet the other's issue-bound k_first / k_trace instead of its own kind (5 runs each on one
         // box: 9.35-9.58 Gsamples/s with the offset, 8.93-9.59 without).
-        const int stagger_pct = tune.stagger_pct;
+        const int stagger_pct = tune.stagger_pct >= 0 ? tune.stagger_pct : (c->sc.use_bvh ? 0 : 50);
         for (size_t s0 = 0, Sb = 0; s0 < (size_t)P->spp; s0 += Sb, bi++) {
             rtw_ctx::Lane& L = c->lane[bi % (size_t)n_lanes];
             hipStream_t ls = L.st;

@@ -89,13 +89,19 @@ struct PathConsts {
     float lnrm[3], larea, lemi[3], pad2;
 };
 
-RTW_DEV void load_trace_part(const PathBuf& B, size_t s, Path& p) {
-    const float4 a = B.p0[s], b = B.p1[s], c = B.p2[s];
+// probes = the scene lists lights: only then can a vertex queue a shadow probe (shade_a), so plane p2 - the probe's
+// direction and length - is neither written nor read in scenes without (16 of a path's 96 bytes, each way)
+RTW_DEV void load_trace_part(const PathBuf& B, size_t s, Path& p, bool probes) {
+    const float4 a = B.p0[s], b = B.p1[s];
     p.o = V(a.x, a.y, a.z); p.d = V(a.w, b.x, b.y); p.ray_time = b.z; p.gk = __float_as_uint(b.w);
-    p.ldir = V(c.x, c.y, c.z); p.ltmax = c.w;
+    p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;
+    if (probes) {
+        const float4 c = B.p2[s];
+        p.ldir = V(c.x, c.y, c.z); p.ltmax = c.w;
+    }
 }
-RTW_DEV void load_path(const PathBuf& B, size_t s, Path& p) {
-    load_trace_part(B, s, p);
+RTW_DEV void load_path(const PathBuf& B, size_t s, Path& p, bool probes) {
+    load_trace_part(B, s, p, probes);
     const float4 d = B.p3[s], e = B.p4[s];
     const uint4 f = B.p5[s];
     p.T = V(d.x, d.y, d.z); p.L = V(d.w, e.x, e.y); p.c = V(e.z, e.w, __uint_as_float(f.x));
@@ -111,10 +117,10 @@ RTW_DEV void load_shade_part(const PathBuf& B, size_t s, Path& p) {
     p.T = V(d.x, d.y, d.z); p.L = V(d.w, e.x, e.y); p.c = V(e.z, e.w, __uint_as_float(f.x));
     p.w0 = f.y; p.a = f.z; p.b = f.w;
 }
-RTW_DEV void store_path(const PathBuf& B, size_t s, const Path& p) {
+RTW_DEV void store_path(const PathBuf& B, size_t s, const Path& p, bool probes) {
     B.p0[s] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
     B.p1[s] = make_float4(p.d.y, p.d.z, p.ray_time, __uint_as_float(p.gk));
-    B.p2[s] = make_float4(p.ldir.x, p.ldir.y, p.ldir.z, p.ltmax);
+    if (probes) B.p2[s] = make_float4(p.ldir.x, p.ldir.y, p.ldir.z, p.ltmax);
     B.p3[s] = make_float4(p.T.x, p.T.y, p.T.z, p.L.x);
     B.p4[s] = make_float4(p.L.y, p.L.z, p.c.x, p.c.y);
     B.p5[s] = make_uint4(__float_as_uint(p.c.z), p.w0, p.a, p.b);
@@ -536,7 +542,7 @@ RTW_DEV void compact_store(const KArgs& A, uint32_t* s_cursor, bool keep, const 
     uint32_t base = 0;
     if ((threadIdx.x & 63u) == 0) base = atomicAdd(&s_cursor[0], (uint32_t)__popcll(ballot));
     base = __builtin_amdgcn_readfirstlane(base);
-    if (keep) store_path(A.out, (size_t)blockIdx.x * A.region_cap + base + before, p);
+    if (keep) store_path(A.out, (size_t)blockIdx.x * A.region_cap + base + before, p, A.sc.n_lights > 0);
 }
 // The trace pass of one path: radiance ray closest hit + queued shadow probe any-hit, result into the hit buffer.
 template <bool DUAL>
@@ -745,7 +751,7 @@ __global__ void __launch_bounds__(kBlock, DUAL ? 8 : RTW_TRACE_BVH_WAVES) k_trac
         const size_t slot = (size_t)region * A.region_cap + chunk * kBlock + tid;
         Path p;
         p.gk = 0; p.ltmax = -1.f;
-        if (valid) load_trace_part(A.in, slot, p);
+        if (valid) load_trace_part(A.in, slot, p, A.sc.n_lights > 0);
         vc += gridDim.x;
         if (vc < wl.total_chunks) worklist_lookup(wl, A.n_regions, vc, region, chunk, n_valid);
         if (valid) trace_path<DUAL>(A, p, slot, tm, n_rays);
@@ -827,7 +833,7 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
                 if (wants && rank < avail) {
                     slot = chunk_base + next + rank;
                     Path p;
-                    load_trace_part(A.in, slot, p);
+                    load_trace_part(A.in, slot, p, A.sc.n_lights > 0);
                     o = p.o; ldir = p.ldir; ltmax = p.ltmax; gt = gather_time_of(A, p.gk);
                     th = 0.f; prim = -1; occl = 0;
                     const bool do_r = !(p.gk & kZombie);
@@ -1052,7 +1058,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
         Path p;
         p.gk = 0; p.ltmax = -1.f;
         if (valid) {
-            load_path(A.in, (size_t)region * A.region_cap + idx, p);
+            load_path(A.in, (size_t)region * A.region_cap + idx, p, A.sc.n_lights > 0);
             Rng<KIND> g;
             rng_from_path<KIND>(g, A.seed, p);
             const float gt = gather_time_of(A, p.gk);
