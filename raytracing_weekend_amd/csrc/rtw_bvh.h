@@ -153,6 +153,7 @@ struct Bvh {
     int max_exp = -100;               // largest grid step of a node is 2^max_exp
     double cost = 0.0;                // steps per ray of the sample walks of walk_cost(): node visits + 1.5 x leaf tests
     int bins = 0;                     // how the BVH2 was split: SAH bins, 0 = full sweep
+    int collapse_kind = 0;            // how it was collapsed (build_bvh_with)
 };
 
 namespace detail {
@@ -256,25 +257,68 @@ inline float node_area(const Node& n) {
 
 // BVH2 -> 4-wide: a node adopts its grandchildren, the child of the largest area first, until it has four children or
 // only leaves. Nodes are numbered breadth-first so that a prefix of the array is the top of the tree.
-inline void collapse(Bvh& out) {
+// optimal = false: greedy, as above. optimal = true: the collapse that minimises the summed surface area of the 4-wide
+// nodes (each area capped at area_cap), by dynamic programming over "this subtree may take i of its parent's slots":
+// cost[n][i] = min(area(n) + best split of 4 slots between n's children,   -- n stays a node (one slot)
+//                  min_j cost[left][j] + cost[right][i - j])               -- n dissolves into its parent
+inline void collapse(Bvh& out, bool optimal = false, float area_cap = FLT_MAX) {
     const std::vector<Node>& nodes = out.nodes;
     std::vector<std::vector<uint32_t>> kids;  // per 4-wide node: BVH2 node indices of its children
     std::vector<uint32_t> src;                // per 4-wide node: the BVH2 node it stands for
     std::vector<int32_t> q4_of(nodes.size(), -1);
     std::vector<uint32_t> queue;
     if (nodes[0].count == 0) queue.push_back(0u);
+    struct Dp { double c[5]; uint8_t split[5]; };  // split[i]: 0 = stays a node, j = left child takes j of the i slots
+    std::vector<Dp> dp;
+    if (optimal) {
+        dp.assign(nodes.size(), Dp{});
+        // children have larger indices than their parent (build() appends them), so a reverse scan is a post-order
+        for (size_t n = nodes.size(); n-- > 0;) {
+            if (nodes[n].count != 0) continue;  // a leaf: one slot, no node cost
+            const uint32_t l = nodes[n].left_first, r = l + 1;
+            auto cost_of = [&](uint32_t x, int i) { return nodes[x].count != 0 ? 0.0 : dp[x].c[i]; };
+            double inner = 1e300;
+            for (int j = 1; j <= 3; j++) inner = std::min(inner, cost_of(l, j) + cost_of(r, 4 - j));
+            const double as_node = (double)std::min(node_area(nodes[n]), area_cap) + inner;
+            dp[n].c[1] = as_node; dp[n].split[1] = 0;
+            for (int i = 2; i <= 4; i++) {
+                dp[n].c[i] = as_node; dp[n].split[i] = 0;
+                for (int j = 1; j < i; j++) {
+                    const double c = cost_of(l, j) + cost_of(r, i - j);
+                    if (c < dp[n].c[i]) { dp[n].c[i] = c; dp[n].split[i] = (uint8_t)j; }
+                }
+            }
+        }
+    }
+    // the children of wide node ni under the optimal collapse: its two BVH2 children given 4 slots
+    auto forest = [&](auto&& self, uint32_t x, int i, std::vector<uint32_t>& ch) -> void {
+        if (nodes[x].count != 0 || dp[x].split[i] == 0) { ch.push_back(x); return; }
+        const int j = dp[x].split[i];
+        self(self, nodes[x].left_first, j, ch);
+        self(self, nodes[x].left_first + 1, i - j, ch);
+    };
     for (size_t q = 0; q < queue.size(); q++) {
         const uint32_t ni = queue[q];
         q4_of[ni] = (int32_t)q;
-        std::vector<uint32_t> ch{nodes[ni].left_first, nodes[ni].left_first + 1};
-        while (ch.size() < 4) {
-            int best = -1; float ba = -1.f;
-            for (size_t k = 0; k < ch.size(); k++)
-                if (nodes[ch[k]].count == 0 && node_area(nodes[ch[k]]) > ba) { ba = node_area(nodes[ch[k]]); best = (int)k; }
-            if (best < 0) break;
-            const uint32_t c = ch[(size_t)best];
-            ch[(size_t)best] = nodes[c].left_first;
-            ch.push_back(nodes[c].left_first + 1);
+        std::vector<uint32_t> ch;
+        if (optimal) {
+            const uint32_t l = nodes[ni].left_first, r = l + 1;
+            auto cost_of = [&](uint32_t x, int i) { return nodes[x].count != 0 ? 0.0 : dp[x].c[i]; };
+            int bj = 1; double bc = 1e300;
+            for (int j = 1; j <= 3; j++) { const double c = cost_of(l, j) + cost_of(r, 4 - j); if (c < bc) { bc = c; bj = j; } }
+            forest(forest, l, bj, ch);
+            forest(forest, r, 4 - bj, ch);
+        } else {
+            ch = {nodes[ni].left_first, nodes[ni].left_first + 1};
+            while (ch.size() < 4) {
+                int best = -1; float ba = -1.f;
+                for (size_t k = 0; k < ch.size(); k++)
+                    if (nodes[ch[k]].count == 0 && node_area(nodes[ch[k]]) > ba) { ba = node_area(nodes[ch[k]]); best = (int)k; }
+                if (best < 0) break;
+                const uint32_t c = ch[(size_t)best];
+                ch[(size_t)best] = nodes[c].left_first;
+                ch.push_back(nodes[c].left_first + 1);
+            }
         }
         for (uint32_t c : ch) if (nodes[c].count == 0) queue.push_back(c);
         kids.push_back(ch); src.push_back(ni);
@@ -390,7 +434,7 @@ inline double walk_cost(const Bvh& t, const std::vector<Item>& items, int n_rays
 }  // namespace detail
 
 // One tree, its BVH2 split by `bins` SAH bins (0 = full sweep).
-inline Bvh build_bvh_with(const rtw_prim* prims, uint32_t n_prims, const rtw_xform* xforms, int bins) {
+inline Bvh build_bvh_with(const rtw_prim* prims, uint32_t n_prims, const rtw_xform* xforms, int bins, int collapse_kind = 0) {
     Bvh out;
     out.bins = bins;
     std::vector<detail::Item> items;
@@ -433,21 +477,34 @@ inline Bvh build_bvh_with(const rtw_prim* prims, uint32_t n_prims, const rtw_xfo
     }
     out.n_slots = (uint32_t)out.leaves.size();
     out.leaves.push_back(LeafRec{});  // a walk reads the slot after a record's first before it knows the kind
-    detail::collapse(out);
+    // collapse_kind 0: greedy; 1: optimal for the plain areas; 2: optimal with areas capped at 16 x the median primitive
+    // box (a stand-in for "a ray that is already inside a huge box visits it whatever its size")
+    float cap = FLT_MAX;
+    if (collapse_kind == 2) {
+        std::vector<float> ar;
+        for (const detail::Item& it : items) ar.push_back(it.b.area());
+        std::nth_element(ar.begin(), ar.begin() + ar.size() / 2, ar.end());
+        cap = 16.0f * ar[ar.size() / 2];
+    }
+    out.collapse_kind = collapse_kind;
+    detail::collapse(out, collapse_kind != 0, cap);
     out.cost = detail::walk_cost(out, items);
     return out;
 }
 
 // The scene's tree. Greedy SAH is not monotone in how finely the splits are searched (measured node visits per ray,
 // 16 bins / 64 bins / sweep: scene 1 7.1 / 6.4 / 7.4, scene 4 7.8 / 8.1 / 6.8), so the three are built - a few
-// thousand primitives, milliseconds - and the 4-wide tree that the sample walks of walk_cost() find cheapest is kept.
+// thousand primitives, milliseconds -, each collapsed greedily and optimally, and the 4-wide tree that the sample walks
+// of walk_cost() find cheapest is kept.
 inline Bvh build_bvh(const rtw_prim* prims, uint32_t n_prims, const rtw_xform* xforms) {
     if (RTW_SAH_BINS >= 0) return build_bvh_with(prims, n_prims, xforms, RTW_SAH_BINS);
-    Bvh best = build_bvh_with(prims, n_prims, xforms, 16);
-    for (int bins : {64, 0}) {
-        Bvh cand = build_bvh_with(prims, n_prims, xforms, bins);
-        if (!cand.q4.empty() && cand.cost < best.cost) best = std::move(cand);
-    }
+    Bvh best = build_bvh_with(prims, n_prims, xforms, 16, 0);
+    for (int kind : {0, 1})
+        for (int bins : {16, 64, 0}) {
+            if (kind == 0 && bins == 16) continue;
+            Bvh cand = build_bvh_with(prims, n_prims, xforms, bins, kind);
+            if (!cand.q4.empty() && cand.cost < best.cost) best = std::move(cand);
+        }
     return best;
 }
 

@@ -225,7 +225,7 @@ struct Tuning {
     size_t pool_paths = (size_t)1 << 28;
     int lanes = 2;
     int grid_mult = 0;   // 0 = automatic
-    int tail_start = 0;  // 0 = automatic: 6 for the brute-list scenes, 20 for tree scenes
+    int tail_start = 0;  // 0 = automatic: 6 for the brute-list scenes, 20 for tree scenes (40 with media)
     bool fused = false;
     bool split_media = true;  // RTW_SPLIT_MEDIA=0: scenes with media keep every bounce in k_bounce
     int brute_max = kBruteMaxPrims;
@@ -717,7 +717,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
         c->n_tree_nodes = bvh.q4.size(); c->n_tree_leaves = bvh.n_slots;
         sc.n_nodes = (int32_t)bvh.q4.size();
         c->lds_bytes = tree_lds_layout(c->n_tree_nodes, c->n_tree_leaves, c->stack_depth, sc.stack_wide != 0, kBlock, tune.lds_kb * 1024, sc.n_lds_nodes, sc.n_lds_leaves);
-        if (tune.verbose) fprintf(stderr, "[rtw] tree (SAH %d, expected node visits %.3f): %zu nodes, %zu leaf records, stack %d x %d bit; LDS %zu B: %d nodes, %d leaf records\n", bvh.bins, bvh.cost,
+        if (tune.verbose) fprintf(stderr, "[rtw] tree (SAH bins %d, collapse %d, sample-walk cost %.3f): %zu nodes, %zu leaf records, stack %d x %d bit; LDS %zu B: %d nodes, %d leaf records\n", bvh.bins, bvh.collapse_kind, bvh.cost,
                                   bvh.q4.size(), (size_t)bvh.n_slots, c->stack_depth, sc.stack_wide ? 32 : 16, c->lds_bytes, sc.n_lds_nodes, sc.n_lds_leaves);
     }
     c->sc = sc;
@@ -969,8 +969,9 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
     std::vector<Step> sched;
     {
         // the fused tail kernel walks the tree one lane per path (lane utilisation 0.2): tree scenes stay in the split
-        // pipeline longer (scene 4: +18 % at 24 vs 6; scenes 1, 2: flat)
-        const int tail_start = tune.tail_start > 0 ? tune.tail_start : (c->sc.use_bvh ? 20 : 6);
+        // pipeline longer, and longest where media keep many paths alive deep (scene 4, 3.9 segments per sample: 20 -> 40
+        // +5 %; scenes 1 and 2, 2.6 and 3.2: best at 20, -2 % at 30)
+        const int tail_start = tune.tail_start > 0 ? tune.tail_start : (c->sc.use_bvh ? (c->sc.n_vol > 0 ? 40 : 20) : 6);
         const bool split = !tune.fused && (c->sc.n_vol == 0 || tune.split_media);
         int d = 0, grp = tune.tail_group, rep = 0;
         while (d < P->max_depth) {
