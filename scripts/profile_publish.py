@@ -6,7 +6,9 @@ src, rnd = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
 for name, out in (("kernel_stats.csv", "kernel_stats.csv"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("pmc_k_path.json", "pmc_k_path.json"),
-                  ("bench.json", "bench.json"), ("bench_configs.jsonl", "bench_configs.jsonl")):
+                  ("bench.json", "bench.json"), ("bench_configs.jsonl", "bench_configs.jsonl"),
+                  ("pmc_k_trace_bvh_scene1.json", "pmc_k_trace_bvh_scene1.json"), ("kernel_stats_scene1.csv", "kernel_stats_scene1.csv"),
+                  ("kernel_stats_scene4.csv", "kernel_stats_scene4.csv")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p):
         shutil.copy(p, os.path.join(dst, f"{rnd}_{out}"))

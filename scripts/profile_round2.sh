@@ -21,4 +21,10 @@ timeout -k 10 600 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
 timeout -k 10 600 python3 scripts/bench_configs.py > $OUT/bench_configs.jsonl 2> $OUT/bench_configs.err
 echo "configs done"
+#   4. tree scenes: counters of k_trace_bvh on scene 1 (BASELINE config 3), kernel-trace statistics of scenes 1 and 4
+bash scripts/pmc_kernel.sh ${TAG}_k_trace_bvh k_trace_bvh 1 1920 1080 256 50 > $OUT/pmc_k_trace_bvh.log 2>&1
+cp gpurun_out/pmc_${TAG}_k_trace_bvh/summary.json $OUT/pmc_k_trace_bvh_scene1.json
+bash scripts/profile_scene.sh ${TAG}_s1 1 1920 1080 512 50 > /dev/null 2>&1 && cp gpurun_out/scene_${TAG}_s1_kernel_stats.csv $OUT/kernel_stats_scene1.csv
+bash scripts/profile_scene.sh ${TAG}_s4 4 1920 1080 128 50 > /dev/null 2>&1 && cp gpurun_out/scene_${TAG}_s4_kernel_stats.csv $OUT/kernel_stats_scene4.csv
+echo "tree scenes done"
 head -c 1500 $OUT/kernel_stats.csv; cut -c1-700 $OUT/bench.json
