@@ -224,3 +224,33 @@ def test_group_context_errors():
     out = np.empty((8, 8, 4), np.float32)
     assert lib.rtw_render(ctx, C.byref(p), out.ctypes.data, None) == -3  # no scene yet
     assert lib.rtw_destroy(ctx) == 0
+
+
+@pytest.mark.parametrize("env", [{}, {"RTW_PATH_TREE": "1"}, {"RTW_LANES": "1", "RTW_TAIL_START": "2"}])
+def test_tree_beyond_16_bit_references(gpu, monkeypatch, env):
+    """9 000 primitives (moving spheres among them, lights, sky): the leaf table has more slots than a 16-bit stack entry
+    can name, so the walk takes its 32-bit form (k_trace_bvh mode 0, the step with branches) - a form no reference scene
+    reaches. Wavefront kernels, k_path_tree, and the fused tail from depth 2 (traverse<>)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    W, H = 48, 36
+    blob = oracle.random_scene(77, W, H, n_prims=9000, motion=True, n_lights=2, sky=True)
+    gpu.upload_scene(blob)
+    p = abi.make_params(W, H, 2, 8)
+    img, st = gpu.render(p)
+    ref, st_ref = oracle.render(blob, p, threads=16)
+    check(img, ref, st, st_ref)
+
+
+@pytest.mark.parametrize("lds_kb", ["6", "60"])
+def test_tree_image_in_lds_or_global(gpu, monkeypatch, lds_kb):
+    """The same 300-primitive tree with almost none of it in the trace kernel's LDS image (mode 1: nodes and leaf slots
+    from global memory) and with all of it (mode 2), moving spheres in their two-slot form."""
+    monkeypatch.setenv("RTW_TRACE_LDS_KB", lds_kb)
+    W, H = 64, 48
+    blob = oracle.random_scene(78, W, H, n_prims=300, motion=True, n_lights=1)
+    gpu.upload_scene(blob)
+    p = abi.make_params(W, H, 3, 12)
+    img, st = gpu.render(p)
+    ref, st_ref = oracle.render(blob, p, threads=16)
+    check(img, ref, st, st_ref)
