@@ -208,6 +208,7 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_BRUTE_MAX   largest primitive count walked with the scalar-cache brute lists (default 24; 0 forces the BVH)
 //   RTW_LDS_KB      dynamic LDS per workgroup for traversal stacks + staged tree nodes (default 16)
 //   RTW_TAIL_GROUP  bounces per launch of the first tail group (default 2; groups grow by half every second launch)
+//   RTW_FIRST_GROUP_LOG2  k_first: 2^n neighbouring threads start samples of one pixel (default 4; 0 = one sample of 64 pixels per wave)
 //   RTW_STAGGER     how far the second lane starts behind the first, in percent of a batch (its first batch is cut short by that
 //                   much; 0 = no offset). Default: 50 for the candidate-list scenes under RTW_PATH=0, 0 for tree scenes (there the
 //                   extra batch costs more than the offset gains: scenes 1, 2, 4 +1-4 % at 512+ spp, +6-13 % at 128-256 spp)
@@ -235,6 +236,9 @@ struct Tuning {
     int trace_waves = 6;         // waves per SIMD it is launched for
     int stagger_pct = -1;  // -1 = automatic
     int tail_group = 2;
+    int first_group_log2 = 4;    // k_first: up to 2^this neighbouring threads take samples of one pixel (RTW_FIRST_GROUP_LOG2; 16:
+                                 // k_first -6 ... -14 %; at 64 the later launches lose more - their finished paths then write
+                                 // 16-byte results npix apart - than k_first gains)
     int path = 1;
     int path_tree = 0;
     int path_job_blocks = 2;
@@ -266,6 +270,7 @@ Tuning read_tuning() {
     if (geti("RTW_TRACE_LDS_KB", v)) t.trace_lds_kb = (size_t)std::max<long long>(0, std::min<long long>(150, v));
     if (geti("RTW_TRACE_WAVES", v)) t.trace_waves = (int)std::max<long long>(1, std::min<long long>(8, v));
     if (geti("RTW_TAIL_GROUP", v)) t.tail_group = (int)std::max<long long>(1, std::min<long long>(64, v));
+    if (geti("RTW_FIRST_GROUP_LOG2", v)) t.first_group_log2 = (int)std::max<long long>(0, std::min<long long>(8, v));
     if (geti("RTW_STAGGER", v)) t.stagger_pct = (int)std::max<long long>(0, std::min<long long>(99, v));
     if (geti("RTW_PATH", v)) t.path = (int)std::max<long long>(0, std::min<long long>(2, v));
     if (geti("RTW_PATH_TREE", v)) t.path_tree = v != 0;
@@ -1034,6 +1039,8 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
             a.sample0 = (uint32_t)(P->sample_offset + (int)s0);
             a.region_cap = (uint32_t)region_cap;
             a.trace_first = split_first ? 1u : 0u;
+            a.first_group_log2 = 0;
+            while (a.first_group_log2 < (uint32_t)tune.first_group_log2 && (Sb >> (a.first_group_log2 + 1)) << (a.first_group_log2 + 1) == Sb) a.first_group_log2++;
             const int grid = (int)regions;  // every compacting launch uses exactly this grid: workgroup b owns region b
             // k_first fills buffer 0 (and the hit buffer); every compacting launch then flips the buffers
             int cur = 0;

@@ -58,6 +58,7 @@ struct KArgs {
     unsigned long long* stats;  // kStatRows rows of 8: [0] segments, [1] shadow probes, [2 + kind] units per kernel kind
     uint32_t n_regions, n_paths, npix, width, height, row0, sample0, seed, depth, max_depth, stack_stride, region_cap, n_iter, trace_first;
     uint32_t row_stride;        // >= 1: local row l of the shard is image row row0 + l*row_stride
+    uint32_t first_group_log2;  // k_first: 2^this consecutive threads take samples of ONE pixel (a power of two dividing the batch)
     uint32_t divw_m, divw_s1, divw_s2;  // exact division by width (multiply-high + shifts)
     uint32_t divs_m, divs_s1, divs_s2;  // exact division by row_stride
     // k_path (register-resident paths with in-wave regeneration)
@@ -664,13 +665,21 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
     uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
     for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
-        const uint32_t path_id = vc * kBlock + tid;
+        // Which camera path a thread starts. Path ids are sample-major (id = sample slot * npix + pixel: what k_resolve
+        // reads), but neighbouring THREADS take 2^first_group_log2 samples of one pixel before the next pixel: a wave's
+        // camera rays then leave through one pixel (or a few) and differ only in their lens sample, so they walk the
+        // tree together and mostly meet the same material. The image cannot depend on this: a path's draws are keyed
+        // by (pixel, sample).
+        const uint32_t t_lin = vc * kBlock + tid;
+        const uint32_t s_lo = t_lin & ((1u << A.first_group_log2) - 1u), q = t_lin >> A.first_group_log2;
+        const uint32_t s_hi = q / A.npix;
+        const uint32_t pl = q - s_hi * A.npix;
+        const uint32_t slot = (s_hi << A.first_group_log2) | s_lo;
+        const uint32_t path_id = slot * A.npix + pl;
         bool keep = false;
         Path p;
         p.gk = 0; p.ltmax = -1.f;
-        if (path_id < A.n_paths) {
-        const uint32_t slot = path_id / A.npix;
-        const uint32_t pl = path_id - slot * A.npix;
+        if (t_lin < A.n_paths) {
         const uint32_t yl = pl / A.width;
         const uint32_t x = pl - yl * A.width;
         const uint32_t y = A.row0 + yl * A.row_stride;
