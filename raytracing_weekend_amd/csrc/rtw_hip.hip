@@ -216,7 +216,8 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //                   regeneration); 0: always the wavefront pipeline
 //   RTW_PATH_TREE   1: tree scenes render through k_path_tree (k_path's idea with a per-lane walk state machine and a vote on the
 //                   kind of step; bit-identical, measured 25-45 % slower than the wavefront kernels on scenes 1, 2, 4); 0 (default): wavefront
-//   RTW_PATH_UNIT_BLOCKS 16-sample blocks a lane takes as one unit in the bulk launch (default 4: 64 samples)
+//   RTW_PATH_UNIT_BLOCKS 16-sample blocks a lane takes as one unit in the bulk launch (default: 8 = 128 samples when a lane has
+//                        600+ blocks to do, else 4)
 //   RTW_PATH_FINE_BLOCKS blocks at the end of a pass that a second, concurrent launch hands out one by one (default 8: 128 samples)
 //   RTW_PATH_JOB_BLOCKS  units per pixel in one k_path job (default 2: a job is 64 pixels x 2 units)
 //   RTW_PATH_GRID_MULT   k_path workgroups per CU (default: what the occupancy query admits)
@@ -242,7 +243,7 @@ struct Tuning {
     int path = 1;
     int path_tree = 0;
     int path_job_blocks = 2;
-    int path_unit_blocks = 4;
+    int path_unit_blocks = 0;    // 0 = automatic (8 for large renders, else 4)
     int path_fine_blocks = 8;
     int path_grid_mult = 0;
     size_t blocksum_bytes = (size_t)16 << 30;
@@ -275,7 +276,7 @@ Tuning read_tuning() {
     if (geti("RTW_PATH", v)) t.path = (int)std::max<long long>(0, std::min<long long>(2, v));
     if (geti("RTW_PATH_TREE", v)) t.path_tree = v != 0;
     if (geti("RTW_PATH_JOB_BLOCKS", v)) t.path_job_blocks = (int)std::max<long long>(1, std::min<long long>(1024, v));
-    if (geti("RTW_PATH_UNIT_BLOCKS", v)) t.path_unit_blocks = (int)std::max<long long>(1, std::min<long long>(4096, v));
+    if (geti("RTW_PATH_UNIT_BLOCKS", v)) t.path_unit_blocks = (int)std::max<long long>(0, std::min<long long>(4096, v));
     if (geti("RTW_PATH_FINE_BLOCKS", v)) t.path_fine_blocks = (int)std::max<long long>(0, std::min<long long>(4096, v));
     if (geti("RTW_PATH_GRID_MULT", v)) t.path_grid_mult = (int)std::max<long long>(1, std::min<long long>(16, v));
     if (geti("RTW_BLOCKSUM_BYTES", v) && v >= (1 << 16)) t.blocksum_bytes = (size_t)v;
@@ -867,7 +868,13 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         // its last `fine_blocks` blocks in single-block units by a SECOND launch on a second stream: its workgroups move into the
         // slots the first launch's workgroups vacate as they run dry, so the machine stays full until only 16-sample units are
         // left (measured on the 1/8 shard of the metric frame: see DESIGN.md section 6).
-        const size_t U = (size_t)tune.path_unit_blocks, F = (size_t)tune.path_fine_blocks;
+        // Unit size: every unit costs a little (queue, camera-ray set-up, a 16-byte store per block either way) and a launch
+        // ends with its longest units, so long renders want long units and short ones short units. Measured on the metric
+        // frame (1 620 blocks per lane): 8-block units 0.556 s, 4-block 0.562 s, 2-block 0.581 s; on its 1/8 shard (202
+        // blocks per lane): 0.0773, 0.0722, 0.0736 s; on the 1/2 shard 8 and 4 are level.
+        const size_t blocks_per_lane = npix * std::min(pass_blocks, n_blocks) / ((size_t)c->n_cu * (size_t)wg_per_cu * kBlock);
+        const size_t U = tune.path_unit_blocks > 0 ? (size_t)tune.path_unit_blocks : (blocks_per_lane >= 600 ? 8 : 4);
+        const size_t F = (size_t)tune.path_fine_blocks;
         for (size_t b0 = 0; b0 < n_blocks; b0 += pass_blocks) {
             const size_t nb = std::min(pass_blocks, n_blocks - b0);
             size_t nb_coarse = nb > 4 * F ? ((nb - F) / U) * U : 0;  // short passes are all fine units
