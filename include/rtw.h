@@ -205,11 +205,17 @@ typedef struct rtw_scene_header {
  * the plain area-measure estimator, emitter hits of listed lights counted only where no light sample stood in for them,
  * media that scatter only inside their extent (Q9), rays started 1e-3 (not 1e-6) away from the hit point.
  * RTW_EST_CORRECTED_NO_NEE is the same integrand estimated without light sampling (every emitter hit counts): slow to
- * converge, but an independent check - both converge to the same image. */
+ * converge, but an independent check - both converge to the same image.
+ * RTW_EST_MIXTURE is the same integrand again, estimated the way the reference's pdf/ callables set out to ("The Rest of
+ * Your Life", mixture_pdf): at a diffuse vertex the scattered direction is drawn from the light list or
+ * from the cosine lobe with probability 1/2 each, the throughput carries albedo * p_cos / (p_cos / 2 + p_light / 2) with
+ * p_light the true solid-angle density of the light list (the reference's rect_*_value stubs return constants), no
+ * shadow probe is traced and every emitter hit counts - one-sample multiple importance sampling, balance heuristic. */
 typedef enum rtw_estimator {
     RTW_EST_REFERENCE = 0,
     RTW_EST_CORRECTED = 1,
-    RTW_EST_CORRECTED_NO_NEE = 2
+    RTW_EST_CORRECTED_NO_NEE = 2,
+    RTW_EST_MIXTURE = 3
 } rtw_estimator;
 
 typedef struct rtw_params {

@@ -759,6 +759,29 @@ static void corrected_lights_free(scene_t* sc) {
     sc->clights = NULL; sc->listed = NULL;
 }
 
+/* RTW_EST_MIXTURE: the solid-angle density, seen from `so`, of "pick one of the nl listed lights uniformly, then a point
+ * on its parallelogram uniformly" in the unit direction w: the sum over the lights whose parallelogram the ray
+ * (so, w) meets of dist^2 / (area |cos|), over nl. What the reference's rect_*_value callables were meant to return
+ * (pdf/rectPdf.cu:75-122 are stubs that return 1e-7 / 1e-8) - "The Rest of Your Life", hittable pdf. */
+static float light_list_pdf(const rtw_light* lights, int nl, v3 so, v3 w) {
+    float sum = 0.0f;
+    for (int i = 0; i < nl; i++) {
+        const rtw_light* lt = &lights[i];
+        const v3 n = ld3(lt->normal), pos = ld3(lt->position), eu = ld3(lt->vec_u), evv = ld3(lt->vec_v);
+        const float denom = dot3(w, n);
+        const float dn = dot3(vsub(pos, so), n);
+        if (denom == 0.0f) continue;
+        const float t = dn / denom;
+        if (!(t > 1.0e-6f)) continue;
+        const v3 rel = vsub(vfma(w, t, so), pos);
+        const float a = dot3(rel, eu) / dot3(eu, eu);
+        const float b = dot3(rel, evv) / dot3(evv, evv);
+        if (!(a >= -1.0e-4f && a <= 1.0001f && b >= -1.0e-4f && b <= 1.0001f)) continue;
+        sum += (t * t) / (lt->area * fabsf(denom));
+    }
+    return sum / (float)nl;
+}
+
 static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int sample, counters_t* cn) {
     const int est = P->estimator;
     int nee_prev = 0; /* RTW_EST_CORRECTED: a light sample was taken at the previous vertex */
@@ -989,6 +1012,33 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
                         }
                     }
                 }
+            } else if (est == RTW_EST_MIXTURE && ev == EV_HIT && !specular && nl > 0 && m->bsdf_eval == 0) {
+                /* The book's estimator ("The Rest of Your Life", mixture_pdf: what pdf/mixturePdf.cu set out to be, Q3 / Q4):
+                 * the scattered direction comes from the light list or from the cosine lobe with probability 1/2 each, the
+                 * throughput carries f cos / pdf = albedo * p_cos / (p_cos / 2 + p_light / 2), no shadow probe is traced and
+                 * every emitter hit counts: one-sample multiple importance sampling with the balance heuristic. */
+                int il = 0;
+                if (nl > 1) {
+                    il = (int)floorf(rng_next(&g, 1) * (float)nl);
+                    if (il < 0) il = 0;
+                    if (il > nl - 1) il = nl - 1;
+                }
+                const float u0 = rng_next(&g, 1);
+                const float ra = rng_next(&g, 1);
+                const float rb = rng_next(&g, 1);
+                if (u0 < 0.5f) {
+                    const rtw_light* lt = &sc->clights[il];
+                    v3 rp = vfma(ld3(lt->vec_v), rb, vfma(ld3(lt->vec_u), ra, ld3(lt->position)));
+                    v3 ldir = vsub(rp, so);
+                    float ldist = length3(ldir);
+                    if (ldist > 1.0e-6f) sd = vscale(ldir, 1.0f / ldist);
+                }
+                const float ndl = dot3(sd, hn);
+                const float pb = fmaxf(0.0f, ndl) * RTW_1_PI_F;
+                const float pl = light_list_pdf(sc->clights, nl, so, sd);
+                const float pm = 0.5f * (pb + pl);
+                if (pb > 0.0f && pm > 0.0f) att = vscale(att, pb / pm);
+                else ev = EV_CANCEL;
             } else if (est == RTW_EST_REFERENCE && ev == EV_HIT && !specular && nl > 0) {
                 int il = 0;
                 if (nl > 1) {
@@ -1048,6 +1098,9 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
         if (2 <= depth) {
             /* raygen.cu:74-82 */
             float p = fmaxf(fmaxf(T.x, T.y), T.z);
+            /* the mixture estimator's weights reach 2, so its throughput can exceed 1: a survival probability is at most 1
+             * (the reference's own throughput never exceeds 1, so its roulette needs no such cap) */
+            if (est == RTW_EST_MIXTURE) p = fminf(p, 1.0f);
             float xi = rng_rr(&g);
             if (!g_debug_no_roulette) {  /* (the draw is consumed either way, so both settings walk the same streams) */
                 if (p < xi) break;
@@ -1109,7 +1162,7 @@ static int check_params(const rtw_params* P) {
     if (!P || P->width <= 0 || P->height <= 0 || P->spp <= 0 || P->max_depth < 0) return RTW_ERR_INVALID_ARG;
     if (P->row0 < 0 || P->row1 > P->height || P->row0 > P->row1 || P->row_stride < 0) return RTW_ERR_INVALID_ARG;
     if (P->rng_kind != RTW_RNG_PHILOX && P->rng_kind != RTW_RNG_TEA_LCG) return RTW_ERR_INVALID_ARG;
-    if (P->estimator < RTW_EST_REFERENCE || P->estimator > RTW_EST_CORRECTED_NO_NEE) return RTW_ERR_INVALID_ARG;
+    if (P->estimator < RTW_EST_REFERENCE || P->estimator > RTW_EST_MIXTURE) return RTW_ERR_INVALID_ARG;
     return RTW_OK;
 }
 
@@ -1121,7 +1174,7 @@ int rtwo_render(const void* blob, size_t bytes, const rtw_params* P, float* rgba
     rc = check_params(P);
     if (rc) return rc;
     if (!rgba_out) return RTW_ERR_INVALID_ARG;
-    if (P->estimator == RTW_EST_CORRECTED && (rc = corrected_lights_build(&sc)) != RTW_OK) { corrected_lights_free(&sc); return rc; }
+    if ((P->estimator == RTW_EST_CORRECTED || P->estimator == RTW_EST_MIXTURE) && (rc = corrected_lights_build(&sc)) != RTW_OK) { corrected_lights_free(&sc); return rc; }
     sc.bounded_media = P->estimator != RTW_EST_REFERENCE;
     int rows = local_rows_of(P);
     if (threads < 1) threads = 1;
@@ -1177,7 +1230,7 @@ int rtwo_trace_pixel(const void* blob, size_t bytes, const rtw_params* P, int px
     int rc = scene_open(&sc, blob, bytes);
     if (rc) return rc;
     counters_t cn = {0, 0};
-    if (P->estimator == RTW_EST_CORRECTED && (rc = corrected_lights_build(&sc)) != RTW_OK) { corrected_lights_free(&sc); return rc; }
+    if ((P->estimator == RTW_EST_CORRECTED || P->estimator == RTW_EST_MIXTURE) && (rc = corrected_lights_build(&sc)) != RTW_OK) { corrected_lights_free(&sc); return rc; }
     sc.bounded_media = P->estimator != RTW_EST_REFERENCE;
     v3 L = trace_path(&sc, P, px, py, sample, &cn);
     corrected_lights_free(&sc);

@@ -19,7 +19,7 @@ RTW_SCENE_VERSION = 1
 RTW_SCENE_MAGIC = 0x57545221
 RTW_RNG_PHILOX = 0
 RTW_RNG_TEA_LCG = 1
-RTW_EST_REFERENCE, RTW_EST_CORRECTED, RTW_EST_CORRECTED_NO_NEE = range(3)
+RTW_EST_REFERENCE, RTW_EST_CORRECTED, RTW_EST_CORRECTED_NO_NEE, RTW_EST_MIXTURE = range(4)
 
 # rtw_prim_type
 PRIM_SPHERE, PRIM_MOVING_SPHERE, PRIM_RECT_X, PRIM_RECT_Y, PRIM_RECT_Z, PRIM_VOLUME_BOX, PRIM_VOLUME_SPHERE = range(7)

@@ -769,8 +769,8 @@ RTW_DEV bool leaf_test(const DScene& sc, const TravMem& tm, uint32_t k, const v3
         const float aa = fma_(tt, da, oa);
         const float bb = fma_(tt, db, ob);
         t = tt;
-        return (tt >= tmin) & (tt < RTW_FLT_MAX) & (aa >= __uint_as_float(a.x)) & (aa <= __uint_as_float(a.y)) & (bb >= __uint_as_float(a.z)) &
-               (bb <= __uint_as_float(a.w));
+        return tt >= tmin && tt < RTW_FLT_MAX && aa >= __uint_as_float(a.x) && aa <= __uint_as_float(a.y) && bb >= __uint_as_float(a.z) &&
+               bb <= __uint_as_float(a.w);
     }
     const int type = (int)(tx & 0xffu);
     rtw_prim pr;

@@ -738,7 +738,7 @@ static int check_render_args(rtw_ctx* c, const rtw_params* P) {
         return fail(c, RTW_ERR_INVALID_ARG, "bad render params");
     if (P->rng_kind != RTW_RNG_PHILOX && P->rng_kind != RTW_RNG_TEA_LCG) return fail(c, RTW_ERR_INVALID_ARG, "bad rng_kind");
     if (P->sample_offset < 0 || P->samples_per_pass < 0 || P->row_stride < 0) return fail(c, RTW_ERR_INVALID_ARG, "bad sample_offset/samples_per_pass/row_stride");
-    if (P->estimator < RTW_EST_REFERENCE || P->estimator > RTW_EST_CORRECTED_NO_NEE) return fail(c, RTW_ERR_INVALID_ARG, "bad estimator");
+    if (P->estimator < RTW_EST_REFERENCE || P->estimator > RTW_EST_MIXTURE) return fail(c, RTW_ERR_INVALID_ARG, "bad estimator");
     return RTW_OK;
 }
 

@@ -200,6 +200,28 @@ struct Nee {
     float tmin, tmax;
 };
 
+// RTW_EST_MIXTURE: the solid-angle density, seen from so, of "one of the nl listed lights uniformly, then a point on its
+// parallelogram uniformly" in the unit direction w (what the reference's rect_*_value stubs, pdf/rectPdf.cu:75-122, were
+// meant to return); the oracle's light_list_pdf, operation for operation.
+RTW_DEV float light_list_pdf(const rtw_light* __restrict__ lights, const int nl, const v3 so, const v3 w) {
+    float sum = 0.0f;
+    for (int i = 0; i < nl; i++) {
+        const rtw_light lt = lights[i];
+        const v3 n = ld3(lt.normal), pos = ld3(lt.position), eu = ld3(lt.vec_u), evv = ld3(lt.vec_v);
+        const float denom = dot3(w, n);
+        const float dn = dot3(vsub(pos, so), n);
+        if (denom == 0.0f) continue;
+        const float t = dn / denom;
+        if (!(t > 1.0e-6f)) continue;
+        const v3 rel = vsub(vfma(w, t, so), pos);
+        const float a = dot3(rel, eu) / dot3(eu, eu);
+        const float b = dot3(rel, evv) / dot3(evv, evv);
+        if (!(a >= -1.0e-4f && a <= 1.0001f && b >= -1.0e-4f && b <= 1.0001f)) continue;
+        sum += (t * t) / (lt.area * __builtin_fabsf(denom));
+    }
+    return sum / (float)nl;
+}
+
 // Closest-hit / miss program up to and including the light sample (shaders/closehit.cu:45-94,
 // miss/miss.cu:8-30, material/*.cu, pdf/mixturePdf.cu:25-38, pdf/rectPdf.cu:124-193).
 // TEX: the instantiation for scenes with non-constant textures or media (the cold features)
@@ -378,6 +400,30 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
                 nee.rad = vscale(vmul(f, lem), k);
             }
         }
+    } else if (est == RTW_EST_MIXTURE && ev == EV_HIT && !specular && nl > 0 && hr.bsdf_eval == 0) {
+        // the book's estimator (rtw.h): direction from the light list or the cosine lobe, probability 1/2 each; the
+        // throughput carries albedo * p_cos / (p_cos / 2 + p_light / 2); no probe, every emitter hit counts
+        int il = 0;
+        if (nl > 1) {
+            il = (int)__builtin_floorf(g.next1() * (float)nl);
+            il = il < 0 ? 0 : (il > nl - 1 ? nl - 1 : il);
+        }
+        const float u0 = g.next1();
+        const float ra = g.next1();
+        const float rb = g.next1();
+        if (u0 < 0.5f) {
+            const rtw_light lt = sc.clights[il];
+            const v3 rp = vfma(ld3(lt.vec_v), rb, vfma(ld3(lt.vec_u), ra, ld3(lt.position)));
+            const v3 ldir = vsub(rp, so);
+            const float ldist = length3(ldir);
+            if (ldist > 1.0e-6f) sd = vscale(ldir, 1.0f / ldist);
+        }
+        const float ndl = dot3(sd, hn);
+        const float pb = __builtin_fmaxf(0.0f, ndl) * RTW_1_PI_F;
+        const float pl = light_list_pdf(sc.clights, nl, so, sd);
+        const float pm = 0.5f * (pb + pl);
+        if (pb > 0.0f && pm > 0.0f) att = vscale(att, pb / pm);
+        else ev = EV_CANCEL;
     } else if (est == RTW_EST_REFERENCE && ev == EV_HIT && !specular && nl > 0) {
         int il = 0;
         if (nl > 1) {
@@ -460,15 +506,18 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
 }
 
 // Tail of rayColor's loop body (raygen.cu:60-84): accumulate, continue or stop, Russian roulette.
+// cap_rr (RTW_EST_MIXTURE): that estimator's weights reach 2, so its throughput can exceed 1 and the survival probability
+// is capped at 1 (the reference's throughput never exceeds 1: its roulette needs no cap and gets none)
 template <int KIND>
 RTW_DEV bool shade_b(const uint32_t depth, const uint32_t max_depth, Rng<KIND>& g, const int ev, const v3 so, const v3 sd, const v3 att,
-                     const v3 radiance, v3& origin, v3& dir, v3& T, v3& L) {
+                     const v3 radiance, v3& origin, v3& dir, v3& T, v3& L, const bool cap_rr = false) {
     L = vadd(L, vmul(radiance, T));  // raygen.cu:60
     if (ev != EV_HIT) return false;
     origin = so; dir = sd;
     T = vmul(T, att);
     if (2u <= depth) {  // raygen.cu:74-82
         float p = __builtin_fmaxf(__builtin_fmaxf(T.x, T.y), T.z);
+        if (cap_rr) p = __builtin_fminf(p, 1.0f);
         if (p < g.rr_draw()) return false;
         T = vscale(T, 1.0f / p);
     }
@@ -718,7 +767,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
                 if (fogged) nee.has = false;
                 else { p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T); }
             }
-            const bool alive = shade_b<KIND>(0u, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L);
+            const bool alive = shade_b<KIND>(0u, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
             p.a = g.a; p.b = g.b;
             if (alive) {
                 p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(1u) : 0.0f;
@@ -806,7 +855,6 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
     int best_prim = -1, prim = -1, sp = 0;
     uint32_t cur = kBvhDone, pend = 0, occl = 0;
     bool shadow_phase = false;
-    NoRng ng;
     const uint32_t root = A.sc.n_tree > 0 ? 0u : kBvhDone;
 #ifdef RTW_TRACE_COUNT
     uint32_t c_inner = 0, c_prim = 0, c_outer = 0, c_winner = 0, c_wleaf = 0;
@@ -1025,7 +1073,7 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
                     if (fogged) nee.has = false;
                     else { p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T); }
                 }
-                const bool alive = shade_b<KIND>(A.depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L);
+                const bool alive = shade_b<KIND>(A.depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
                 if (ev == EV_HIT) p.o = so;  // a queued probe starts at the hit point even when the path stops here
                 p.a = g.a; p.b = g.b;
                 if (alive) {
@@ -1102,7 +1150,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                         n_shadow++;
                         if (sprim < 0) radiance = vadd(radiance, nee.rad);
                     }
-                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L);
+                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
                     depth++;
                     if (!alive) break;
                     p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(depth) : 0.0f;
@@ -1336,7 +1384,7 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
                 if (sprim < 0) radiance = vadd(radiance, nee.rad);
             }
             RTW_MARK("shade_b");
-            alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L);
+            alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
             depth++;
             rng_a = g.a;
             if (alive) {
@@ -1423,7 +1471,6 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
     int sp = 0, best_prim = -1;
     float best_t = 0.f, tmin = 0.f, wtime = 0.f;
     v3 wd = o, inv = o;
-    NoRng ng;
     uint32_t n_seg = 0, n_shadow = 0;
 #ifdef RTW_PHASE_TIMERS
     unsigned long long ph_cyc[6] = {0, 0, 0, 0, 0, 0}, ph_t0 = __builtin_amdgcn_s_memtime();
@@ -1509,7 +1556,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
                         }
                         if (!fogged) { ldir = nee.dir; ltmax = nee.tmax; c = vmul(nee.rad, T); }
                     }
-                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L);
+                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
                     if (ev == EV_HIT) o = so;  // a pending probe starts at the hit point even when the path stops here
                     depth++;
                     rng_a = g.a; rng_b = g.b;

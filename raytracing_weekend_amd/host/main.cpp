@@ -59,8 +59,8 @@ int main(int argc, char* argv[]) {
     -seed N        RNG seed
     -rng K         philox (default) or lcg (the reference's tea+lcg generator)
     -denoise N     N passes (1..8) of the a-trous filter that stands in for the reference's AI denoiser (default: off)
-    -est K         reference (default: the reference's estimator, quirks included), corrected, or brute
-                   (corrected without light sampling)
+    -est K         reference (default: the reference's estimator, quirks included), corrected, brute
+                   (corrected without light sampling) or mixture (the book's 50/50 mixture of light and cosine sampling)
     -cam K         perspective (default), environment or orthographic (the reference's two unused camera kinds, scene/ioCamera.h:118-179)
     -gpu N         Device ordinal (the first one with -gpus)
     -gpus N        Render on N GPUs of this node: interleaved row shards, one gather onto the first device (default 1)
@@ -99,6 +99,7 @@ int main(int argc, char* argv[]) {
     const std::string& estName = cl_input.getCmdOption("-est");
     if (estName == "corrected") estimator = RTW_EST_CORRECTED;
     else if (estName == "brute") estimator = RTW_EST_CORRECTED_NO_NEE;
+    else if (estName == "mixture") estimator = RTW_EST_MIXTURE;
     else if (!estName.empty() && estName != "reference") std::cerr << "WARNING: unknown -est " << estName << ", using reference" << std::endl;
 
     int camKind = RTW_CAM_PERSPECTIVE;

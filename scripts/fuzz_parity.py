@@ -23,7 +23,7 @@ for seed in range(first, first + n):
     w, h = int(rs.randint(9, 120)), int(rs.randint(9, 90))
     blob = oracle.random_scene(seed, w, h, **kw)
     p = abi.make_params(w, h, int(rs.randint(1, 9)), int(rs.choice([1, 2, 5, 12, 50])), rng_kind=int(rs.randint(2)),
-                        seed=int(rs.randint(1, 1 << 31)), estimator=int(rs.choice([0, 0, 1, 2])), sample_offset=int(rs.choice([0, 0, 7])))
+                        seed=int(rs.randint(1, 1 << 31)), estimator=int(rs.choice([0, 0, 1, 2, 3])), sample_offset=int(rs.choice([0, 0, 7])))
     if small:
         p.estimator = 0
         p.spp = int(rs.choice([1, 3, 63, 64, 65, 130, 200]))

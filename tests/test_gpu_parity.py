@@ -235,7 +235,7 @@ def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
         monkeypatch.delenv(n, raising=False)
 
 
-@pytest.mark.parametrize("est", [abi.RTW_EST_CORRECTED, abi.RTW_EST_CORRECTED_NO_NEE])
+@pytest.mark.parametrize("est", [abi.RTW_EST_CORRECTED, abi.RTW_EST_CORRECTED_NO_NEE, abi.RTW_EST_MIXTURE])
 def test_corrected_estimators_match_oracle(gpu, est):
     """the corrected estimators (cosine sampling, per-light area sampling without the heuristic weight,
     emitter hits not double counted, 1e-3 ray offsets) - bit-exact against the oracle like the reference mode."""
@@ -259,12 +259,13 @@ def test_corrected_estimators_match_oracle(gpu, est):
 
 
 def test_corrected_estimators_agree_with_each_other(gpu):
-    """Light sampling and brute-force emitter hits estimate the same integrand: at 16K / 128K samples per pixel the block
+    """Light sampling, the 50/50 mixture and brute-force emitter hits estimate the same integrand: at 16K / 128K samples per pixel the block
     means of a 64x64 Cornell box agree within 2 %, the image means within 0.5 %; the reference estimator does not
     (it is ~20 % darker in the mean: stray factor 2, self-intersections, heuristic weights without their complement)."""
     w = h = 64
     gpu.upload_scene(abi.build_scene(0, w, h))
     nee, _ = gpu.render(abi.make_params(w, h, 16384, 50, estimator=abi.RTW_EST_CORRECTED))
+    mix, _ = gpu.render(abi.make_params(w, h, 65536, 50, estimator=abi.RTW_EST_MIXTURE))  # (half its directions go to the cosine lobe: ~4x the variance per sample)
     brute, _ = gpu.render(abi.make_params(w, h, 131072, 50, estimator=abi.RTW_EST_CORRECTED_NO_NEE))
     ref, _ = gpu.render(abi.make_params(w, h, 16384, 50))
 
@@ -275,6 +276,11 @@ def test_corrected_estimators_agree_with_each_other(gpu):
     lit = blocks(brute) > 0.02
     rel = np.abs(blocks(nee) - blocks(brute))[lit] / blocks(brute)[lit]
     assert rel.max() < 0.02, rel.max()
+    # the book's 50/50 mixture of light and cosine sampling (RTW_EST_MIXTURE) estimates that integrand too
+    m_mix = mix[..., :3].astype(np.float64).mean()
+    assert abs(m_mix - m_brute) / m_brute < 5e-3, (m_mix, m_brute)
+    rel = np.abs(blocks(mix) - blocks(brute))[lit] / blocks(brute)[lit]
+    assert rel.max() < 0.03, rel.max()
     assert abs(m_ref - m_brute) / m_brute > 0.05
 
 

@@ -243,7 +243,7 @@ def test_corrected_estimators_on_the_oracle():
     lib = oracle.load()
     out = np.zeros((h, w, 4), np.float32)
     st = abi.Stats()
-    for bad in (-1, 3):
+    for bad in (-1, 4):
         p = abi.make_params(w, h, 1, 2, estimator=bad)
         assert lib.rtwo_render(blob, len(blob), C.byref(p), out.ctypes.data, C.byref(st), 1) == -1
 

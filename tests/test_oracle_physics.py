@@ -226,3 +226,17 @@ print("asan-ok")
     env = dict(os.environ, LD_PRELOAD=asan + (":" + ubsan if os.path.exists(ubsan) else ""), ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "asan-ok" in r.stdout, r.stderr[-3000:]
+
+
+def test_mixture_estimator_agrees_with_light_sampling_in_the_mean():
+    """RTW_EST_MIXTURE (direction from the light list or the cosine lobe with probability 1/2, weight albedo * p_cos / p_mix,
+    no probe, every emitter hit counts) and RTW_EST_CORRECTED (area-measure light samples) estimate one integrand: the
+    means of a 32x32 Cornell box at 2048 spp agree within 1 % (measured 0.1 %; without the cap on the roulette's survival
+    probability the mixture came out 6 % dark - its weights reach 2)."""
+    w = h = 32
+    blob = abi.build_scene(0, w, h)
+    nee, _ = oracle.render(blob, abi.make_params(w, h, 2048, 50, estimator=abi.RTW_EST_CORRECTED), threads=8)
+    mix, st = oracle.render(blob, abi.make_params(w, h, 2048, 50, estimator=abi.RTW_EST_MIXTURE), threads=8)
+    assert st.shadow_rays == 0
+    m_nee, m_mix = (a[..., :3].astype(np.float64).mean() for a in (nee, mix))
+    assert abs(m_mix - m_nee) / m_nee < 0.01, (m_mix, m_nee)
