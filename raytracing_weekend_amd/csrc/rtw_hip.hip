@@ -309,14 +309,17 @@ TraceBvhKernel trace_bvh_kernel(int block, int mode) {
 enum { LK_FIRST = RTW_K_FIRST, LK_SHADE = RTW_K_SHADE, LK_TRACE = RTW_K_TRACE, LK_BOUNCE = RTW_K_BOUNCE, LK_PATH = RTW_K_PATH, LK_PATH_TREE = RTW_K_COUNT };
 void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipStream_t s, int block = kBlock) {
     const bool lcg = rng_kind == RTW_RNG_TEA_LCG;
-    // kernels that shade exist in four instantiations: RNG kind x "some material has a non-constant texture"
-    const bool tex = a.sc.has_tex != 0;
+    // kernels that shade exist in six instantiations: RNG kind x feature level
+    const int feat = a.sc.has_tex;  // 0 hot, 1 cold features, 2 cold features + the mixture estimator (rtw_kernels.h shade_a)
+#define RTW_LAUNCH_SHADING_R(K_, LDS_, R_)                                                                        \
+    do {                                                                                                          \
+        if (feat == 2) hipLaunchKernelGGL((K_<R_, 2>), dim3(grid), dim3(kBlock), LDS_, s, a);                     \
+        else if (feat == 1) hipLaunchKernelGGL((K_<R_, 1>), dim3(grid), dim3(kBlock), LDS_, s, a);                \
+        else hipLaunchKernelGGL((K_<R_, 0>), dim3(grid), dim3(kBlock), LDS_, s, a);                               \
+    } while (0)
 #define RTW_LAUNCH_SHADING(K_, LDS_)                                                                              \
     do {                                                                                                          \
-        if (lcg) { if (tex) hipLaunchKernelGGL((K_<RTW_RNG_TEA_LCG, true>), dim3(grid), dim3(kBlock), LDS_, s, a); \
-                   else hipLaunchKernelGGL((K_<RTW_RNG_TEA_LCG, false>), dim3(grid), dim3(kBlock), LDS_, s, a); }  \
-        else { if (tex) hipLaunchKernelGGL((K_<RTW_RNG_PHILOX, true>), dim3(grid), dim3(kBlock), LDS_, s, a);      \
-               else hipLaunchKernelGGL((K_<RTW_RNG_PHILOX, false>), dim3(grid), dim3(kBlock), LDS_, s, a); }       \
+        if (lcg) RTW_LAUNCH_SHADING_R(K_, LDS_, RTW_RNG_TEA_LCG); else RTW_LAUNCH_SHADING_R(K_, LDS_, RTW_RNG_PHILOX); \
     } while (0)
     switch (which) {
     case LK_FIRST: RTW_LAUNCH_SHADING(k_first, lds); break;
@@ -330,6 +333,7 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
     case LK_PATH_TREE: RTW_LAUNCH_SHADING(k_path_tree, lds); break;
     default: RTW_LAUNCH_SHADING(k_bounce, lds); break;
 #undef RTW_LAUNCH_SHADING
+#undef RTW_LAUNCH_SHADING_R
     }
 }
 
@@ -798,7 +802,7 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
     KArgs base{};
     base.sc = c->sc;
     if (P->estimator != RTW_EST_REFERENCE) {  // the corrected estimators live in the cold-feature instantiations
-        base.sc.estimator = P->estimator; base.sc.has_tex = 1;
+        base.sc.estimator = P->estimator; base.sc.has_tex = P->estimator == RTW_EST_MIXTURE ? 2 : 1;
         base.sc.ray_tmin = 1.0e-3f; base.sc.probe_eps = 1.0e-3f;
     }
     base.npix = (uint32_t)npix;
@@ -834,15 +838,17 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         int wg_per_cu = tune.path_grid_mult;
         const size_t path_lds = path_tree ? lds : 0;
         if (wg_per_cu <= 0) {
-            const bool lcg = P->rng_kind == RTW_RNG_TEA_LCG, tex = base.sc.has_tex != 0;
+            const bool lcg = P->rng_kind == RTW_RNG_TEA_LCG;
+            const int feat = base.sc.has_tex;
             int nb = 0;
             hipError_t qe;
-#define RTW_OCC(K_) (lcg ? (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<RTW_RNG_TEA_LCG, true>, kBlock, path_lds)   \
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<RTW_RNG_TEA_LCG, false>, kBlock, path_lds)) \
-                         : (tex ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<RTW_RNG_PHILOX, true>, kBlock, path_lds)    \
-                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<RTW_RNG_PHILOX, false>, kBlock, path_lds)))
+#define RTW_OCC_R(K_, R_) (feat == 2 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<R_, 2>, kBlock, path_lds)   \
+                           : feat == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<R_, 1>, kBlock, path_lds) \
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<R_, 0>, kBlock, path_lds))
+#define RTW_OCC(K_) (lcg ? RTW_OCC_R(K_, RTW_RNG_TEA_LCG) : RTW_OCC_R(K_, RTW_RNG_PHILOX))
             if (path_tree) qe = RTW_OCC(k_path_tree); else qe = RTW_OCC(k_path);
 #undef RTW_OCC
+#undef RTW_OCC_R
             wg_per_cu = (qe == hipSuccess && nb > 0) ? std::min(nb, 8) : 4;
         }
         const size_t n_groups = (npix + 63) / 64;

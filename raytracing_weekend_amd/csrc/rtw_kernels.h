@@ -224,8 +224,10 @@ RTW_DEV float light_list_pdf(const rtw_light* __restrict__ lights, const int nl,
 
 // Closest-hit / miss program up to and including the light sample (shaders/closehit.cu:45-94,
 // miss/miss.cu:8-30, material/*.cu, pdf/mixturePdf.cu:25-38, pdf/rectPdf.cu:124-193).
-// TEX: the instantiation for scenes with non-constant textures or media (the cold features)
-template <int KIND, bool TEX>
+// TEX: 0 = the hot instantiation; 1 = the one for scenes with non-constant textures or media and for the corrected
+// estimators (the cold features); 2 = 1 + the mixture estimator (its light-list pdf loop costs the others registers:
+// inlined into instantiation 1 it put 20 bytes of scratch into k_shade and k_path and 4-7 % onto scenes 2, 3 and 4)
+template <int KIND, int TEX>
 RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 dir, const float gather_time, const float t, const int prim,
                     v3& so, v3& sd, v3& att, v3& radiance, Nee& nee, const uint32_t* noise_lds, uint32_t& nee_prev, const u32x4* hr_lds = nullptr,
                     const PathConsts* pc = nullptr) {
@@ -400,7 +402,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
                 nee.rad = vscale(vmul(f, lem), k);
             }
         }
-    } else if (est == RTW_EST_MIXTURE && ev == EV_HIT && !specular && nl > 0 && hr.bsdf_eval == 0) {
+    } else if (TEX == 2 && est == RTW_EST_MIXTURE && ev == EV_HIT && !specular && nl > 0 && hr.bsdf_eval == 0) {
         // the book's estimator (rtw.h): direction from the light list or the cosine lobe, probability 1/2 each; the
         // throughput carries albedo * p_cos / (p_cos / 2 + p_light / 2); no probe, every emitter hit counts
         int il = 0;
@@ -702,14 +704,14 @@ RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const ui
 }
 
 // ------------------------------------------------------------------ k_first
-template <int KIND, bool TEX>
+template <int KIND, int TEX>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_CURSOR_SHARED
     RTW_NOISE_SHARED
     const uint32_t tid = threadIdx.x;
     cursor_init(s_cursor);
-    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
+    const uint32_t* noise_lds = stage_noise<(TEX != 0)>(A.sc, s_noise);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
@@ -767,7 +769,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
                 if (fogged) nee.has = false;
                 else { p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T); }
             }
-            const bool alive = shade_b<KIND>(0u, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
+            const bool alive = shade_b<KIND>(0u, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX == 2 && A.sc.estimator == RTW_EST_MIXTURE);
             p.a = g.a; p.b = g.b;
             if (alive) {
                 p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(1u) : 0.0f;
@@ -1011,14 +1013,14 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
 #ifndef RTW_SHADE_WAVES
 #define RTW_SHADE_WAVES RTW_MIN_WAVES
 #endif
-template <int KIND, bool TEX>
+template <int KIND, int TEX>
 __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A) {
     RTW_WORKLIST_SHARED
     RTW_CURSOR_SHARED
     RTW_NOISE_SHARED
     const uint32_t tid = threadIdx.x;
     cursor_init(s_cursor);
-    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
+    const uint32_t* noise_lds = stage_noise<(TEX != 0)>(A.sc, s_noise);
     uint32_t n_seg = 0, n_shadow = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
     // the work-list lookup of the next chunk (a dependent chain of LDS reads) is issued behind this chunk's loads
@@ -1073,7 +1075,7 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
                     if (fogged) nee.has = false;
                     else { p.ldir = nee.dir; p.ltmax = nee.tmax; p.c = vmul(nee.rad, p.T); }
                 }
-                const bool alive = shade_b<KIND>(A.depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
+                const bool alive = shade_b<KIND>(A.depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX == 2 && A.sc.estimator == RTW_EST_MIXTURE);
                 if (ev == EV_HIT) p.o = so;  // a queued probe starts at the hit point even when the path stops here
                 p.a = g.a; p.b = g.b;
                 if (alive) {
@@ -1094,7 +1096,7 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
 }
 
 // ------------------------------------------------------------------ k_bounce (fused)
-template <int KIND, bool TEX>
+template <int KIND, int TEX>
 __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_WORKLIST_SHARED
@@ -1102,7 +1104,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
     RTW_NOISE_SHARED
     const uint32_t tid = threadIdx.x;
     cursor_init(s_cursor);
-    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
+    const uint32_t* noise_lds = stage_noise<(TEX != 0)>(A.sc, s_noise);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     uint32_t n_seg = 0, n_shadow = 0;
     const WorkList wl = worklist_init(A.cnt_in, A.n_regions, s_pref, s_part);
@@ -1150,7 +1152,7 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_bounce(const KArgs A)
                         n_shadow++;
                         if (sprim < 0) radiance = vadd(radiance, nee.rad);
                     }
-                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
+                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, p.o, p.d, p.T, p.L, TEX == 2 && A.sc.estimator == RTW_EST_MIXTURE);
                     depth++;
                     if (!alive) break;
                     p.ray_time = (KIND == RTW_RNG_TEA_LCG || A.sc.has_motion) ? g.ray_time(depth) : 0.0f;
@@ -1253,12 +1255,12 @@ RTW_DEV constexpr int rtw_phase_id(const char* n) { return n[0] == 'r' && n[2] =
 #ifndef RTW_PATH_WAVES
 #define RTW_PATH_WAVES 5
 #endif
-template <int KIND, bool TEX>
+template <int KIND, int TEX>
 __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) k_path(const KArgs A) {
     RTW_NOISE_SHARED
     __shared__ u32x4 s_hitrec[kPathMaxPrims * 6];
     const uint32_t tid = threadIdx.x;
-    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
+    const uint32_t* noise_lds = stage_noise<(TEX != 0)>(A.sc, s_noise);
     {   // the hit records of a small scene live in LDS for the whole launch
         const u32x4* src = (const u32x4*)A.sc.hitrec;
         for (uint32_t i = tid; i < (uint32_t)A.sc.n_prims * 6u; i += kBlock) s_hitrec[i] = src[i];
@@ -1384,7 +1386,7 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
                 if (sprim < 0) radiance = vadd(radiance, nee.rad);
             }
             RTW_MARK("shade_b");
-            alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
+            alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L, TEX == 2 && A.sc.estimator == RTW_EST_MIXTURE);
             depth++;
             rng_a = g.a;
             if (alive) {
@@ -1440,12 +1442,12 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
 #ifndef RTW_TREE_WAVES
 #define RTW_TREE_WAVES RTW_MIN_WAVES
 #endif
-template <int KIND, bool TEX>
+template <int KIND, int TEX>
 __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_NOISE_SHARED
     const uint32_t tid = threadIdx.x;
-    const uint32_t* noise_lds = stage_noise<TEX>(A.sc, s_noise);
+    const uint32_t* noise_lds = stage_noise<(TEX != 0)>(A.sc, s_noise);
     const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
     const uint32_t lane = tid & 63u;
     const uint32_t root = A.sc.n_tree > 0 ? 0u : kBvhDone;
@@ -1556,7 +1558,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
                         }
                         if (!fogged) { ldir = nee.dir; ltmax = nee.tmax; c = vmul(nee.rad, T); }
                     }
-                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L, TEX && A.sc.estimator == RTW_EST_MIXTURE);
+                    alive = shade_b<KIND>(depth, A.max_depth, g, ev, so, sd, att, radiance, o, d, T, L, TEX == 2 && A.sc.estimator == RTW_EST_MIXTURE);
                     if (ev == EV_HIT) o = so;  // a pending probe starts at the hit point even when the path stops here
                     depth++;
                     rng_a = g.a; rng_b = g.b;
