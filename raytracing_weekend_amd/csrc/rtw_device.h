@@ -748,15 +748,19 @@ RTW_DEV bool leaf_test(const DScene& sc, const TravMem& tm, uint32_t k, const v3
     const uint32_t tx = b.z;  // type | xform << 8
     next = k + ((tx & 0xffu) == (uint32_t)RTW_PRIM_MOVING_SPHERE ? 2u : 1u);
     const v3 c0 = V(__uint_as_float(a.x), __uint_as_float(a.y), __uint_as_float(a.z));
-    if (tx == (uint32_t)RTW_PRIM_SPHERE)  // geometry/sphere.cu:52-60,93-95
-        return sphere_roots(o, d, c0, __uint_as_float(a.w), tmin, RTW_FLT_MAX, t);
-    if (tx == (uint32_t)RTW_PRIM_MOVING_SPHERE) {
-        // the matrix-motion transform translate(lerp(C0, C1, rayTime)) (geometry/ioMovingSphere.h:161-203) and, on top
-        // of it, the program's own centre at the gather time (geometry/movingSphere.cu:33-39): object_ray + prim_test
-        const v3 dc = vsub(V(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)), c0);
-        const float t0 = __uint_as_float(b.x), t1 = __uint_as_float(b.w);
-        const v3 oo = vsub(o, vfma(dc, ray_time, c0));
-        const v3 ctr = t0 == t1 ? c0 : vfma(dc, (gather_time - t0) / (t1 - t0), c0);
+    if (tx <= (uint32_t)RTW_PRIM_MOVING_SPHERE) {  // RTW_PRIM_SPHERE (0) or RTW_PRIM_MOVING_SPHERE (1), untransformed
+        // One call of the intersection program (geometry/sphere.cu:52-60,93-95) for both kinds - a wave that holds both
+        // would otherwise run its square root and divisions twice - on per-lane (origin, centre): a static sphere's are
+        // the ray's and its own; a moving sphere's are the ray under the matrix-motion transform
+        // translate(lerp(C0, C1, rayTime)) (geometry/ioMovingSphere.h:161-203) and the program's own centre at the gather
+        // time (geometry/movingSphere.cu:33-39): what object_ray + prim_test compute.
+        v3 oo = o, ctr = c0;
+        if (tx == (uint32_t)RTW_PRIM_MOVING_SPHERE) {
+            const v3 dc = vsub(V(__uint_as_float(c.x), __uint_as_float(c.y), __uint_as_float(c.z)), c0);
+            const float t0 = __uint_as_float(b.x), t1 = __uint_as_float(b.w);
+            oo = vsub(o, vfma(dc, ray_time, c0));
+            if (t0 != t1) ctr = vfma(dc, (gather_time - t0) / (t1 - t0), c0);
+        }
         return sphere_roots(oo, d, ctr, __uint_as_float(a.w), tmin, RTW_FLT_MAX, t);
     }
     if (tx - (uint32_t)RTW_PRIM_RECT_X <= (uint32_t)(RTW_PRIM_RECT_Z - RTW_PRIM_RECT_X)) {

@@ -832,6 +832,9 @@ __global__ void __launch_bounds__(kBlock, DUAL ? 8 : RTW_TRACE_BVH_WAVES) k_trac
 #ifndef RTW_LEAF_BIAS
 #define RTW_LEAF_BIAS 1
 #endif
+#ifndef RTW_LEAF_BIAS_DEN
+#define RTW_LEAF_BIAS_DEN 1
+#endif
 // MODE 0: 32-bit stack entries (trees beyond 8 K references; the step with branches); 1: 16-bit entries, nodes beyond the
 // LDS image come from global memory; 2: 16-bit entries and every node in LDS (the walk loop then holds no global load,
 // so the stores of finished rays and the loads of a refill are never waited for inside it)
@@ -928,7 +931,7 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
         bool at_inner = active && (cur & 3u) == 0u;
         for (;;) {
             const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
-            if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_act - n_in) break;
+            if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < (n_act - n_in) * (uint32_t)RTW_LEAF_BIAS_DEN) break;
             if (at_inner) {
                 if (MODE == 0) {
                     cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
@@ -1611,7 +1614,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
         bool at_inner = walking && (cur & 3u) == 0u;
         for (;;) {
             const uint32_t n_in = (uint32_t)__popcll(__ballot(at_inner));
-            if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < n_walk - n_in) break;
+            if (n_in == 0u || n_in * (uint32_t)RTW_LEAF_BIAS < (n_walk - n_in) * (uint32_t)RTW_LEAF_BIAS_DEN) break;
             if (at_inner) {
                 if (tm.wide) {
                     cur = bvh_inner_step(A.sc, tm, o, inv, tmin, best_t, cur, sp);
