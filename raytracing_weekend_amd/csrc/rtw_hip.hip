@@ -202,12 +202,15 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_POOL_PATHS  paths in flight over all lanes (default 2^28: 55 GiB of state, sized for 288 GB of HBM)
 //   RTW_LANES       stream lanes that overlap consecutive batches (default 2; 1..4)
 //   RTW_GRID_MULT   persistent workgroups per CU (default 8 with one lane, 4 with two)
-//   RTW_TAIL_START  first bounce handled by the fused multi-bounce tail launches (default 6; 20 for tree scenes)
+//   RTW_TAIL_START  first bounce handled by the fused multi-bounce tail launches (default 6; 20 for tree scenes, 40 for tree scenes with media)
 //   RTW_FUSED=1     every bounce through the fused k_bounce
 //   RTW_SPLIT_MEDIA=0  scenes with media: every bounce through k_bounce (default: split pipeline, volumes tested in the shading kernels)
 //   RTW_BRUTE_MAX   largest primitive count walked with the scalar-cache brute lists (default 24; 0 forces the BVH)
 //   RTW_LDS_KB      dynamic LDS per workgroup for traversal stacks + staged tree nodes (default 16)
 //   RTW_TAIL_GROUP  bounces per launch of the first tail group (default 2; groups grow by half every second launch)
+//   RTW_PAIRED=1    tree scenes, two lanes: batches run in pairs whose trace launches alternate, so that a k_trace_bvh always has the
+//                   other batch's k_shade beside it (measured 12 % slower than the free-running lanes: off; RTW_PAIRED_TRACE_WAVES
+//                   = waves per SIMD of the trace kernel in that mode, default 4)
 //   RTW_FIRST_GROUP_LOG2  k_first: 2^n neighbouring threads start samples of one pixel (default 4; 0 = one sample of 64 pixels per wave)
 //   RTW_STAGGER     how far the second lane starts behind the first, in percent of a batch (its first batch is cut short by that
 //                   much; 0 = no offset). Default: 50 for the candidate-list scenes under RTW_PATH=0, 0 for tree scenes (there the
@@ -237,6 +240,8 @@ struct Tuning {
     int trace_waves = 6;         // waves per SIMD it is launched for
     int stagger_pct = -1;  // -1 = automatic
     int tail_group = 2;
+    bool paired = false;         // RTW_PAIRED=1: tree scenes, two lanes: the batches of a pair alternate their trace launches
+    int paired_trace_waves = 4;  // RTW_PAIRED_TRACE_WAVES: waves per SIMD of k_trace_bvh then (room for the other batch's k_shade)
     int first_group_log2 = 4;    // k_first: up to 2^this neighbouring threads take samples of one pixel (RTW_FIRST_GROUP_LOG2; 16:
                                  // k_first -6 ... -14 %; at 64 the later launches lose more - their finished paths then write
                                  // 16-byte results npix apart - than k_first gains)
@@ -272,6 +277,8 @@ Tuning read_tuning() {
     if (geti("RTW_TRACE_WAVES", v)) t.trace_waves = (int)std::max<long long>(1, std::min<long long>(8, v));
     if (geti("RTW_TAIL_GROUP", v)) t.tail_group = (int)std::max<long long>(1, std::min<long long>(64, v));
     if (geti("RTW_FIRST_GROUP_LOG2", v)) t.first_group_log2 = (int)std::max<long long>(0, std::min<long long>(8, v));
+    if (geti("RTW_PAIRED", v)) t.paired = v != 0;
+    if (geti("RTW_PAIRED_TRACE_WAVES", v)) t.paired_trace_waves = (int)std::max<long long>(1, std::min<long long>(8, v));
     if (geti("RTW_STAGGER", v)) t.stagger_pct = (int)std::max<long long>(0, std::min<long long>(99, v));
     if (geti("RTW_PATH", v)) t.path = (int)std::max<long long>(0, std::min<long long>(2, v));
     if (geti("RTW_PATH_TREE", v)) t.path_tree = v != 0;
@@ -958,6 +965,8 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         const size_t g = grid_for(paths);
         return ((chunks + g - 1) / g + 2) * (size_t)kBlock;
     };
+    // RTW_PAIRED: batches run two at a time with their trace launches alternating (see the batch loop)
+    const bool paired = tune.paired && n_lanes == 2 && c->sc.use_bvh;
     // k_trace_bvh: large workgroups share one LDS copy of the tree (nodes, then leaf records) between more waves
     const int trace_block = tune.trace_block;
     int32_t trace_nodes = 0, trace_leaves = 0;
@@ -968,7 +977,7 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
                                     trace_nodes, trace_leaves);
         const size_t per_wg = trace_lds + (kMaxRegions + 1 + (size_t)trace_block) * 4 + 64;
         const size_t by_lds = std::max<size_t>(1, (size_t)160 * 1024 / per_wg);
-        const size_t by_waves = std::max<size_t>(1, (size_t)(4 * tune.trace_waves) / ((size_t)trace_block / 64));
+        const size_t by_waves = std::max<size_t>(1, (size_t)(4 * (paired ? tune.paired_trace_waves : tune.trace_waves)) / ((size_t)trace_block / 64));
         trace_grid = (int)((size_t)c->n_cu * std::min(by_lds, by_waves));
         if (trace_lds > 48 * 1024) {  // beyond the default dynamic-LDS limit of a launch
             DScene ts = c->sc;
@@ -1031,70 +1040,125 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         // k_shade launches then meet the other's issue-bound k_first / k_trace instead of its own kind (5 runs each on one
         // box: 9.35-9.58 Gsamples/s with the offset, 8.93-9.59 without).
         const int stagger_pct = tune.stagger_pct >= 0 ? tune.stagger_pct : (c->sc.use_bvh ? 0 : 50);
-        for (size_t s0 = 0, Sb = 0; s0 < (size_t)P->spp; s0 += Sb, bi++) {
-            rtw_ctx::Lane& L = c->lane[bi % (size_t)n_lanes];
-            hipStream_t ls = L.st;
+        // One batch in flight on a lane: its arguments and which of the lane's two path buffers is current.
+        struct BatchRun { rtw_ctx::Lane* L; KArgs a; int cur; size_t ci; uint32_t regions; size_t Sb, s0; };
+        auto batch_size = [&](size_t b, size_t s0_) {
             size_t want = S;
-            if (stagger_pct > 0 && bi > 0 && bi < (size_t)n_lanes && S > 1)  // lane k starts k/n_lanes of a batch late (at 50 %)
-                want = std::max<size_t>(1, S - S * bi * (size_t)stagger_pct * 2 / (100 * (size_t)n_lanes));
-            Sb = std::min(want, (size_t)P->spp - s0);
-            const size_t paths = npix * Sb;
-            const uint32_t regions = grid_for(paths);
-            const size_t region_cap = cap_for(paths);
+            if (stagger_pct > 0 && b > 0 && b < (size_t)n_lanes && S > 1)  // lane k starts k/n_lanes of a batch late (at 50 %)
+                want = std::max<size_t>(1, S - S * b * (size_t)stagger_pct * 2 / (100 * (size_t)n_lanes));
+            return std::min(want, (size_t)P->spp - s0_);
+        };
+        // camera rays (+ the primary segment) of a batch on its lane
+        auto begin_batch = [&](size_t b, size_t s0_, size_t Sb_, BatchRun& R) -> hipError_t {
+            R.L = &c->lane[b % (size_t)n_lanes]; R.Sb = Sb_; R.s0 = s0_;
+            rtw_ctx::Lane& L = *R.L;
+            const size_t paths = npix * Sb_;
+            R.regions = grid_for(paths);
             // this lane's pool is free again once the resolve of its previous batch has run on the main stream
-            HIP_TRY_C(hipStreamWaitEvent(ls, bi < (size_t)n_lanes ? ev_ready : L.ev_free, 0));
-            HIP_TRY_C(hipMemsetAsync(L.cnt, 0, (size_t)regions * (sched.size() + 2) * sizeof(uint32_t), ls));
-            KArgs a = base;
+            hipError_t er = hipStreamWaitEvent(L.st, b < (size_t)n_lanes ? ev_ready : L.ev_free, 0);
+            if (er == hipSuccess) er = hipMemsetAsync(L.cnt, 0, (size_t)R.regions * (sched.size() + 2) * sizeof(uint32_t), L.st);
+            if (er != hipSuccess) return er;
+            KArgs& a = R.a;
+            a = base;
             a.lbuf = L.lbuf;
             a.stats = c->d_stats;
-            a.n_regions = regions;
+            a.n_regions = R.regions;
             a.n_paths = (uint32_t)paths;
-            a.sample0 = (uint32_t)(P->sample_offset + (int)s0);
-            a.region_cap = (uint32_t)region_cap;
+            a.sample0 = (uint32_t)(P->sample_offset + (int)s0_);
+            a.region_cap = (uint32_t)cap_for(paths);
             a.trace_first = split_first ? 1u : 0u;
             a.first_group_log2 = 0;
-            while (a.first_group_log2 < (uint32_t)tune.first_group_log2 && (Sb >> (a.first_group_log2 + 1)) << (a.first_group_log2 + 1) == Sb) a.first_group_log2++;
-            const int grid = (int)regions;  // every compacting launch uses exactly this grid: workgroup b owns region b
+            while (a.first_group_log2 < (uint32_t)tune.first_group_log2 && (Sb_ >> (a.first_group_log2 + 1)) << (a.first_group_log2 + 1) == Sb_) a.first_group_log2++;
             // k_first fills buffer 0 (and the hit buffer); every compacting launch then flips the buffers
-            int cur = 0;
-            size_t ci = 0;  // index of the region-counter row describing buffer `cur`
+            R.cur = 0;
+            R.ci = 0;  // index of the region-counter row describing buffer `cur`
             a.out = L.buf[0];
             a.hit_out = L.hit[0];
             a.cnt_out = L.cnt;
             a.depth = 0; a.n_iter = 1;
-            HIP_TRY_C(timed_launch(ls, LK_FIRST, a, grid, lds));
             launches++;
-            for (size_t si = 0; si < sched.size(); si++) {
-                const Step& st = sched[si];
-                a.in = L.buf[cur];
-                a.hit = L.hit[cur];
-                a.hit_out = L.hit[cur];  // k_trace fills the records of the buffer it reads
-                a.cnt_in = L.cnt + ci * regions;
-                a.depth = (uint32_t)st.depth;
-                a.n_iter = (uint32_t)st.n_iter;
-                if (st.kind == LK_TRACE) {
-                    if (c->sc.use_bvh) {  // its own workgroup size, LDS image and grid: waves own streams of chunks, not regions
-                        KArgs at = a;
-                        at.sc.n_lds_nodes = trace_nodes; at.sc.n_lds_leaves = trace_leaves;
-                        HIP_TRY_C(timed_launch(ls, LK_TRACE, at, trace_grid, trace_lds, trace_block));
-                    } else {
-                        HIP_TRY_C(timed_launch(ls, LK_TRACE, a, grid, lds));
-                    }
+            return timed_launch(L.st, LK_FIRST, a, (int)R.regions, lds);  // every compacting launch uses exactly this grid: workgroup b owns region b
+        };
+        // step si of the schedule for a batch; a trace launch may wait for an event of the other lane and record one
+        auto run_step = [&](BatchRun& R, size_t si, hipEvent_t wait_for, hipEvent_t record) -> hipError_t {
+            rtw_ctx::Lane& L = *R.L;
+            KArgs& a = R.a;
+            const Step& st = sched[si];
+            const int grid = (int)R.regions;
+            a.in = L.buf[R.cur];
+            a.hit = L.hit[R.cur];
+            a.hit_out = L.hit[R.cur];  // k_trace fills the records of the buffer it reads
+            a.cnt_in = L.cnt + R.ci * R.regions;
+            a.depth = (uint32_t)st.depth;
+            a.n_iter = (uint32_t)st.n_iter;
+            hipError_t er = hipSuccess;
+            if (wait_for) er = hipStreamWaitEvent(L.st, wait_for, 0);
+            if (er != hipSuccess) return er;
+            if (st.kind == LK_TRACE) {
+                if (c->sc.use_bvh) {  // its own workgroup size, LDS image and grid: waves own streams of chunks, not regions
+                    KArgs at = a;
+                    at.sc.n_lds_nodes = trace_nodes; at.sc.n_lds_leaves = trace_leaves;
+                    er = timed_launch(L.st, LK_TRACE, at, trace_grid, trace_lds, trace_block);
                 } else {
-                    a.out = L.buf[cur ^ 1];
-                    a.hit_out = L.hit[cur ^ 1];
-                    a.cnt_out = L.cnt + (ci + 1) * regions;
-                    HIP_TRY_C(timed_launch(ls, st.kind, a, grid, st.kind == LK_BOUNCE ? lds : 0));
-                    cur ^= 1;
-                    ci++;
+                    er = timed_launch(L.st, LK_TRACE, a, grid, lds);
                 }
-                launches++;
+            } else {
+                a.out = L.buf[R.cur ^ 1];
+                a.hit_out = L.hit[R.cur ^ 1];
+                a.cnt_out = L.cnt + (R.ci + 1) * R.regions;
+                er = timed_launch(L.st, st.kind, a, grid, st.kind == LK_BOUNCE ? lds : 0);
+                R.cur ^= 1;
+                R.ci++;
             }
-            HIP_TRY_C(hipEventRecord(L.ev_done, ls));
+            launches++;
+            if (er == hipSuccess && record) er = hipEventRecord(record, L.st);
+            return er;
+        };
+        auto end_batch = [&](BatchRun& R) -> hipError_t {
+            rtw_ctx::Lane& L = *R.L;
+            hipError_t er = hipEventRecord(L.ev_done, L.st);
             // batches are resolved into the accumulators in order, on the main stream
-            HIP_TRY_C(hipStreamWaitEvent(s, L.ev_done, 0));
-            hipLaunchKernelGGL(k_resolve, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)L.lbuf, c->accum, c->part, (uint32_t)npix, (uint32_t)Sb, (uint32_t)s0);
-            HIP_TRY_C(hipEventRecord(L.ev_free, s));
+            if (er == hipSuccess) er = hipStreamWaitEvent(s, L.ev_done, 0);
+            if (er != hipSuccess) return er;
+            hipLaunchKernelGGL(k_resolve, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)L.lbuf, c->accum, c->part, (uint32_t)npix, (uint32_t)R.Sb, (uint32_t)R.s0);
+            return hipEventRecord(L.ev_free, s);
+        };
+        for (size_t s0 = 0; s0 < (size_t)P->spp;) {
+            BatchRun A;
+            const size_t SbA = batch_size(bi, s0);
+            HIP_TRY_C(begin_batch(bi, s0, SbA, A));
+            const size_t s1 = s0 + SbA;
+            if (paired && s1 < (size_t)P->spp) {
+                // Two batches in step: the trace launches of the pair never run at the same time - each starts when the
+                // other batch's trace launch of the same depth (or of the depth before) has ended - so an issue-bound
+                // k_trace_bvh always has a bandwidth-bound k_shade of the other batch beside it and not its own kind.
+                BatchRun B;
+                const size_t SbB = batch_size(bi + 1, s1);
+                HIP_TRY_C(begin_batch(bi + 1, s1, SbB, B));
+                hipEvent_t ev_prev = nullptr;
+                for (size_t si = 0; si < sched.size(); si++) {
+                    if (sched[si].kind == LK_TRACE) {
+                        hipEvent_t ea = nullptr, eb = nullptr;
+                        HIP_TRY_C(new_event(ea));
+                        HIP_TRY_C(new_event(eb));
+                        HIP_TRY_C(run_step(A, si, ev_prev, ea));
+                        HIP_TRY_C(run_step(B, si, ea, eb));
+                        ev_prev = eb;
+                    } else {
+                        HIP_TRY_C(run_step(A, si, nullptr, nullptr));
+                        HIP_TRY_C(run_step(B, si, nullptr, nullptr));
+                    }
+                }
+                HIP_TRY_C(end_batch(A));
+                HIP_TRY_C(end_batch(B));
+                s0 = s1 + SbB;
+                bi += 2;
+            } else {
+                for (size_t si = 0; si < sched.size(); si++) HIP_TRY_C(run_step(A, si, nullptr, nullptr));
+                HIP_TRY_C(end_batch(A));
+                s0 = s1;
+                bi++;
+            }
         }
     }
     hipLaunchKernelGGL(k_finish, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->accum, (const float4*)c->part, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);

@@ -199,7 +199,7 @@ def test_textured_scene_through_the_fused_path(gpu):
 
 def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
     """Pipeline (k_path with paths in registers vs the wavefront kernels), lanes, pool size, tail start, fused vs split
-    (with and without media), LDS budget, grid size, k_first's sample grouping, the trace kernel's workgroup size and LDS image,
+    (with and without media), LDS budget, grid size, k_first's sample grouping, the trace kernel's workgroup size and LDS image, the paired batch schedule,
     job and unit size, the fine-grained end-game launch, block-sum passes:
     tuning knobs move work between kernels, lanes and streams, never a bit of the image or a count."""
     cases = [(abi.build_scene(0, 96, 64), 96, 64, 150, 30), (abi.build_scene(3, 64, 64), 64, 64, 10, 30),
@@ -210,7 +210,8 @@ def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
             {"RTW_LDS_KB": "48", "RTW_BRUTE_MAX": "0"}, {"RTW_POOL_PATHS": "4096", "RTW_GRID_MULT": "3"},
             {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "0"}, {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "30"},
             {"RTW_FIRST_GROUP_LOG2": "0"}, {"RTW_FIRST_GROUP_LOG2": "6", "RTW_POOL_PATHS": "200000"},
-            {"RTW_TRACE_BLOCK": "512", "RTW_TRACE_LDS_KB": "40"}, {"RTW_TRACE_WAVES": "3", "RTW_TRACE_LDS_KB": "5"}]
+            {"RTW_TRACE_BLOCK": "512", "RTW_TRACE_LDS_KB": "40"}, {"RTW_TRACE_WAVES": "3", "RTW_TRACE_LDS_KB": "5"},
+            {"RTW_PAIRED": "1", "RTW_POOL_PATHS": "30000"}, {"RTW_PAIRED": "1", "RTW_PAIRED_TRACE_WAVES": "6", "RTW_POOL_PATHS": "9000"}]
     knobs = [{}, {"RTW_PATH_TREE": "1"}, {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_PATH_JOB_BLOCKS": "1", "RTW_PATH_GRID_MULT": "1"},
              {"RTW_PATH_JOB_BLOCKS": "7", "RTW_BLOCKSUM_BYTES": "65536"}, {"RTW_PATH_GRID_MULT": "2", "RTW_KERNEL_TIMING": "0"},
              {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_LDS_KB": "0"}, {"RTW_PATH_TREE": "1", "RTW_LDS_KB": "40"},
