@@ -180,3 +180,17 @@ def test_camera_kinds_of_the_host_description():
     assert np.isfinite(img).all()
     with pytest.raises(ValueError):
         abi.build_scene(300, 8, 8)
+
+
+def test_tree_builder_invariants(tmp_path):
+    """The GPU's tree builder (csrc/rtw_bvh.h, host code) checked on the CPU by tests/native/bvh_check.cpp: every surface
+    primitive owns one leaf record (moving spheres two slots), quantised boxes only ever grow (a chain of containing boxes leads
+    from the root to every primitive's leaf), a walk that culls with them finds what a scan finds, for all six candidate builds
+    of the five reference scenes and two synthetic ones; build_bvh keeps the cheapest by its sample walks."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bvh_check")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-o", exe, os.path.join(root, "tests", "native", "bvh_check.cpp"), "-ldl"])
+    out = subprocess.run([exe, abi.HOST_LIB, "0", "1", "2", "3", "4", "100", "2000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.count("scene ") == 7
