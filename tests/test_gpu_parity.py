@@ -525,6 +525,12 @@ def test_cli_director_outputs(tmp_path):
     blob = abi.build_scene(0, w, h)
     ref, _ = oracle.render(blob, abi.make_params(w, h, spp, depth), threads=8)
     assert np.array_equal(img, ref[..., :3])
+    # -est: the estimator reaches rtw_params (the mixture estimator's image is the oracle's, and not the reference's)
+    pfm_mix = str(tmp_path / "mix.pfm")
+    subprocess.run(args + ["-est", "mixture", "-o", pfm_mix], check=True, timeout=300)
+    img_mix = np.frombuffer(open(pfm_mix, "rb").read()[len(head):], dtype="<f4").reshape(h, w, 3)
+    ref_mix, _ = oracle.render(blob, abi.make_params(w, h, spp, depth, estimator=abi.RTW_EST_MIXTURE), threads=8)
+    assert np.array_equal(img_mix, ref_mix[..., :3]) and not np.array_equal(img_mix, img)
     # -gpus 3: three interleaved shards inside the library (all on this box's one GPU), gathered: the same file
     pfm3 = str(tmp_path / "o3.pfm")
     subprocess.run(args + ["-gpus", "3", "-o", pfm3], check=True, timeout=300, env=dict(os.environ, RTW_SAME_DEVICE="1"))
