@@ -18,6 +18,8 @@
 //   p0 = origin.xyz, dir.x      p1 = dir.yz, ray_time, gk (24-bit gather-time fraction | zombie bit 31)
 //   p2 = shadow dir.xyz, shadow tmax (<0: none queued)
 //   p3 = T.xyz, L.x             p4 = L.yz, c.xy          p5 = c.z, w0, rng a, rng b
+// (scenes without listed lights queue no probes: p2 is not used, p4 = L.yz, w0, rng a, and rng b alone takes p5's place as a
+// plane of dwords: 68 bytes per path)
 // c is the queued light-sample contribution (already multiplied by the throughput of its segment); it
 // is added to L by the next k_shade if the shadow probe found no occluder, before anything else
 // touches L, so the floating-point order of the reference's `sampleRadiance += radiance*throughput`
@@ -101,30 +103,45 @@ RTW_DEV void load_trace_part(const PathBuf& B, size_t s, Path& p, bool probes) {
         p.ldir = V(c.x, c.y, c.z); p.ltmax = c.w;
     }
 }
+// Planes p3 ... p5 of a path. With probes: p3 = T.xyz, L.x; p4 = L.yz, c.xy; p5 = c.z, w0, a, b. Without (no listed light: c is
+// never set): p3 the same; p4 = L.yz, w0, a; and b alone in a plane of dwords that takes p5's place (the same allocation read
+// as uint32[]) - 36 bytes instead of 48, each way, in the kernels that run at the HBM copy rate.
+RTW_DEV void load_state_part(const PathBuf& B, size_t s, Path& p, bool probes) {
+    const float4 d = B.p3[s], e = B.p4[s];
+    p.T = V(d.x, d.y, d.z);
+    if (probes) {
+        const uint4 f = B.p5[s];
+        p.L = V(d.w, e.x, e.y); p.c = V(e.z, e.w, __uint_as_float(f.x));
+        p.w0 = f.y; p.a = f.z; p.b = f.w;
+    } else {
+        p.L = V(d.w, e.x, e.y); p.c = V(0.f, 0.f, 0.f);
+        p.w0 = __float_as_uint(e.z); p.a = __float_as_uint(e.w); p.b = ((const uint32_t*)B.p5)[s];
+    }
+}
 RTW_DEV void load_path(const PathBuf& B, size_t s, Path& p, bool probes) {
     load_trace_part(B, s, p, probes);
-    const float4 d = B.p3[s], e = B.p4[s];
-    const uint4 f = B.p5[s];
-    p.T = V(d.x, d.y, d.z); p.L = V(d.w, e.x, e.y); p.c = V(e.z, e.w, __uint_as_float(f.x));
-    p.w0 = f.y; p.a = f.z; p.b = f.w;
+    load_state_part(B, s, p, probes);
 }
 // k_shade's view: everything but the queued probe's direction (plane p2 belongs to k_trace; whether a probe was
 // queued and what it found comes back in the hit record)
-RTW_DEV void load_shade_part(const PathBuf& B, size_t s, Path& p) {
-    const float4 a = B.p0[s], b = B.p1[s], d = B.p3[s], e = B.p4[s];
-    const uint4 f = B.p5[s];
+RTW_DEV void load_shade_part(const PathBuf& B, size_t s, Path& p, bool probes) {
+    const float4 a = B.p0[s], b = B.p1[s];
     p.o = V(a.x, a.y, a.z); p.d = V(a.w, b.x, b.y); p.ray_time = b.z; p.gk = __float_as_uint(b.w);
     p.ldir = V(0.f, 0.f, 0.f); p.ltmax = -1.0f;
-    p.T = V(d.x, d.y, d.z); p.L = V(d.w, e.x, e.y); p.c = V(e.z, e.w, __uint_as_float(f.x));
-    p.w0 = f.y; p.a = f.z; p.b = f.w;
+    load_state_part(B, s, p, probes);
 }
 RTW_DEV void store_path(const PathBuf& B, size_t s, const Path& p, bool probes) {
     B.p0[s] = make_float4(p.o.x, p.o.y, p.o.z, p.d.x);
     B.p1[s] = make_float4(p.d.y, p.d.z, p.ray_time, __uint_as_float(p.gk));
-    if (probes) B.p2[s] = make_float4(p.ldir.x, p.ldir.y, p.ldir.z, p.ltmax);
     B.p3[s] = make_float4(p.T.x, p.T.y, p.T.z, p.L.x);
-    B.p4[s] = make_float4(p.L.y, p.L.z, p.c.x, p.c.y);
-    B.p5[s] = make_uint4(__float_as_uint(p.c.z), p.w0, p.a, p.b);
+    if (probes) {
+        B.p2[s] = make_float4(p.ldir.x, p.ldir.y, p.ldir.z, p.ltmax);
+        B.p4[s] = make_float4(p.L.y, p.L.z, p.c.x, p.c.y);
+        B.p5[s] = make_uint4(__float_as_uint(p.c.z), p.w0, p.a, p.b);
+    } else {
+        B.p4[s] = make_float4(p.L.y, p.L.z, __uint_as_float(p.w0), __uint_as_float(p.a));
+        ((uint32_t*)B.p5)[s] = p.b;
+    }
 }
 
 // ------------------------------------------------------------------ work list
@@ -1071,7 +1088,7 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
             __syncthreads();
             if (valid) {
                 const size_t slot = base_slot + s_sort_perm[tid];
-                load_shade_part(A.in, slot, p);
+                load_shade_part(A.in, slot, p, A.sc.n_lights > 0);
                 h = A.hit[slot];
             }
             // (no barrier is needed before the next chunk's sort: its counts are written while at most s_sort_perm is still being
@@ -1080,7 +1097,7 @@ __global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A
 #else
         if (valid) {
             const size_t slot = (size_t)region * A.region_cap + chunk * kBlock + tid;
-            load_shade_part(A.in, slot, p);
+            load_shade_part(A.in, slot, p, A.sc.n_lights > 0);
             h = A.hit[slot];
         }
 #endif
