@@ -167,7 +167,8 @@ typedef struct rtw_pdf {
  *   RTW_CAM_ENVIRONMENT   origin; a = (cos(2 pi s) sin(pi t), -cos(pi t), sin(2 pi s) sin(pi t)); direction = normalize(a.x u + a.y v + a.z w)
  *   RTW_CAM_ORTHOGRAPHIC  origin = lower_left + s*horizontal + t*vertical + camera origin (as camera.cuh:52 states it: the origin
  *                         enters twice when lower_left is built the way ioOrthographicCamera builds it); direction = -normalize(w)
- * The two lens draws of the raygen program are consumed whatever the kind. */
+ * Only the perspective camera draws a lens sample (two draws, consumed even at lens radius 0: camera.cu:11-19); the other
+ * two take no seed in the reference and draw nothing (visible in the TEA+LCG stream; Philox raygen draws are positional). */
 typedef enum rtw_camera_type { RTW_CAM_PERSPECTIVE = 0, RTW_CAM_ENVIRONMENT = 1, RTW_CAM_ORTHOGRAPHIC = 2 } rtw_camera_type;
 
 typedef struct rtw_camera {
@@ -248,7 +249,7 @@ typedef struct rtw_stats {
     /* per kernel kind, measured with HIP events recorded on the launch stream around every launch */
     double kernel_seconds[RTW_K_COUNT];
     uint64_t kernel_launches[RTW_K_COUNT];
-    uint64_t kernel_segments[RTW_K_COUNT]; /* radiance segments shaded by that kernel (k_trace: rays traced) */
+    uint64_t kernel_segments[RTW_K_COUNT]; /* radiance segments shaded by that kernel (k_trace: path slots traced = a radiance ray and / or its queued probe) */
 } rtw_stats;
 
 typedef struct rtw_ctx rtw_ctx;

@@ -802,9 +802,13 @@ static v3 trace_path(const scene_t* sc, const rtw_params* P, int px, int py, int
     /* raygen.cu:134-135 */
     float s = ((float)px + rng_next(&g, 0)) / (float)P->width;
     float t = ((float)py + rng_next(&g, 0)) / (float)P->height;
-    /* shaders/camera.cu:11-19 + sampling.cuh:15-22 : two draws even when the lens radius is 0 */
-    float la = rng_next(&g, 0);
-    float lb = rng_next(&g, 0);
+    /* shaders/camera.cu:11-19 + sampling.cuh:15-22 : the perspective camera draws twice even when the lens radius is 0;
+     * the environment and orthographic cameras (scene/camera.cuh:35-56) take no seed and draw nothing */
+    float la = 0.0f, lb = 0.0f;
+    if (H->camera_type == RTW_CAM_PERSPECTIVE) {
+        la = rng_next(&g, 0);
+        lb = rng_next(&g, 0);
+    }
     v3 origin = ld3(cam->origin);
     if (cam->lens_radius != 0.0f) {
         float sn, cs;

@@ -29,6 +29,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -89,6 +94,24 @@ struct rtw_ctx {
     std::vector<rtw_ctx*> kids;
     float4* stage = nullptr;
     size_t stage_pix = 0;
+    struct Worker* worker = nullptr;  // a kid's host thread: created with the group, lives until rtw_destroy
+};
+
+// One persistent host thread per kid context of a group (n_devices > 1). The caller's thread hands it one shard per render
+// call and waits; no thread is created or joined per call.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv;
+    bool has_job = false, done = false, quit = false;
+    // the job (written by the caller's thread before has_job is set, read by the worker; results the other way)
+    rtw_params P{};
+    size_t npix = 0;
+    float4* gather_dst = nullptr;  // where the shard goes on the group's first device
+    int gather_dev = 0;
+    bool want_stats = false;
+    rtw_stats st{};
+    int rc = RTW_OK;
 };
 
 namespace {
@@ -337,22 +360,56 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
         else hipLaunchKernelGGL((k_trace<false>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
     case LK_PATH: RTW_LAUNCH_SHADING(k_path, lds); break;
+#ifdef RTW_EXPERIMENTS
     case LK_PATH_TREE: RTW_LAUNCH_SHADING(k_path_tree, lds); break;
+#endif
     default: RTW_LAUNCH_SHADING(k_bounce, lds); break;
 #undef RTW_LAUNCH_SHADING
 #undef RTW_LAUNCH_SHADING_R
     }
 }
 
-}  // namespace
+// ---- the exception barrier of the C ABI (include/rtw.h: "no exceptions cross this ABI") -------------------------------
+// The implementations below use std::vector / std::string / std::thread and may throw (bad_alloc, system_error). Every
+// extern "C" entry point runs its implementation inside guarded(): an exception becomes an error code and a message, as the
+// reference's OPTIX_CHECK / CUDA_CHECK exceptions (Director.cpp:106-122) become the Director's exit path.
+int fail_nothrow(rtw_ctx* c, int code, const char* msg) noexcept {
+    if (c) {
+        try { c->err.assign(msg); } catch (...) { c->err.clear(); }  // (clear() does not allocate)
+    }
+    return code;
+}
+// Test hook (tests/test_abi.py, tests/test_gpu_round3.py): RTW_TEST_FAULT="<where>:<kind>" makes the named point of the library
+// throw (kind bad_alloc | runtime), so that the barrier and the worker threads' containment can be exercised on purpose.
+// where: entry (every entry point, before its arguments are looked at), upload (after the scene tables are staged),
+// worker (inside a group's worker thread, before its render).
+void test_fault(const char* where) {
+    const char* e = getenv("RTW_TEST_FAULT");
+    if (!e || !*e) return;
+    const size_t n = strlen(where);
+    if (strncmp(e, where, n) != 0 || e[n] != ':') return;
+    if (strcmp(e + n + 1, "bad_alloc") == 0) throw std::bad_alloc();
+    throw std::runtime_error(std::string("injected fault at ") + where);
+}
+template <class F>
+int guarded(rtw_ctx* c, F&& f) noexcept {
+    try {
+        test_fault("entry");
+        return f();
+    } catch (const std::bad_alloc&) {
+        return fail_nothrow(c, RTW_ERR_OOM, "out of host memory (std::bad_alloc)");
+    } catch (const std::exception& e) {
+        return fail_nothrow(c, RTW_ERR_DEVICE, e.what());
+    } catch (...) {
+        return fail_nothrow(c, RTW_ERR_DEVICE, "unknown exception");
+    }
+}
 
-extern "C" {
+int impl_destroy(rtw_ctx* c);
+int impl_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_stream, rtw_stats* stats);
+void worker_main(rtw_ctx* kc);
 
-int rtw_abi_version(void) { return RTW_ABI_VERSION; }
-
-const char* rtw_last_error(rtw_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-
-static int create_single(rtw_ctx** out, int device) {
+int create_single(rtw_ctx** out, int device) {
     rtw_ctx* c = new (std::nothrow) rtw_ctx();
     if (!c) return RTW_ERR_OOM;
     c->device = device;
@@ -368,9 +425,7 @@ static int create_single(rtw_ctx** out, int device) {
     return RTW_OK;
 }
 
-int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids) {
-    if (!out) return RTW_ERR_INVALID_ARG;
-    *out = nullptr;
+int impl_create(rtw_ctx** out, int n_devices, const int* device_ids) {
     if (n_devices < 1 || n_devices > 64) return RTW_ERR_INVALID_ARG;
     rtw_ctx* c = nullptr;
     int rc = create_single(&c, device_ids ? device_ids[0] : 0);
@@ -380,8 +435,16 @@ int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids) {
         for (int g = 0; g < n_devices; g++) {
             rtw_ctx* k = nullptr;
             rc = create_single(&k, device_ids ? device_ids[g] : g);
-            if (rc) { rtw_destroy(c); return rc; }
-            c->kids.push_back(k);
+            if (rc) { impl_destroy(c); return rc; }
+            try {
+                c->kids.push_back(k);
+            } catch (...) { impl_destroy(k); impl_destroy(c); throw; }
+            // the kid's host thread, for the lifetime of the group (std::thread's constructor may throw std::system_error:
+            // the caller's guard turns that into an error code once the half-built group is gone)
+            try {
+                k->worker = new Worker();
+                k->worker->th = std::thread(worker_main, k);
+            } catch (...) { impl_destroy(c); throw; }
             if (k->device != c->device) {  // direct peer copies for the gather where the link allows them; not an error if not
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, c->device, k->device) == hipSuccess && can) {
@@ -397,10 +460,22 @@ int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids) {
     return RTW_OK;
 }
 
-int rtw_destroy(rtw_ctx* c) {
+int impl_destroy(rtw_ctx* c) {
     if (!c) return RTW_ERR_INVALID_ARG;
-    for (rtw_ctx* k : c->kids) (void)rtw_destroy(k);
+    for (rtw_ctx* k : c->kids) (void)impl_destroy(k);
     c->kids.clear();
+    if (c->worker) {
+        if (c->worker->th.joinable()) {
+            {
+                std::lock_guard<std::mutex> lk(c->worker->m);
+                c->worker->quit = true;
+            }
+            c->worker->cv.notify_all();
+            c->worker->th.join();
+        }
+        delete c->worker;
+        c->worker = nullptr;
+    }
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     free_pool(c);
@@ -425,12 +500,12 @@ int rtw_destroy(rtw_ctx* c) {
     return RTW_OK;
 }
 
-int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
+int impl_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!c) return RTW_ERR_INVALID_ARG;
     if (!c->kids.empty()) {  // group: every device gets its own copy of the scene tables and the tree
         c->has_scene = false;
         for (rtw_ctx* k : c->kids) {
-            const int rc = rtw_upload_scene(k, blob, bytes);
+            const int rc = impl_upload_scene(k, blob, bytes);
             if (rc) return fail(c, rc, k->err);
         }
         c->has_scene = true;
@@ -670,6 +745,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!texdata.empty()) memcpy(stage.data() + o_texdata, texdata.data(), texdata.size() * sizeof(uint32_t));
     if (!walk.empty()) memcpy(stage.data() + o_walk, walk.data(), walk.size() * sizeof(uint32_t));
 
+    test_fault("upload");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_scene) { (void)hipFree(c->d_scene); c->d_scene = nullptr; }
@@ -742,7 +818,7 @@ int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     return RTW_OK;
 }
 
-static int check_render_args(rtw_ctx* c, const rtw_params* P) {
+int check_render_args(rtw_ctx* c, const rtw_params* P) {
     if (!c->has_scene) return fail(c, RTW_ERR_NO_SCENE, "rtw_render before rtw_upload_scene");
     if (!P) return fail(c, RTW_ERR_INVALID_ARG, "null params");
     if (P->width <= 0 || P->height <= 0 || P->spp <= 0 || P->max_depth < 0 || P->row0 < 0 || P->row1 > P->height || P->row0 > P->row1)
@@ -753,13 +829,13 @@ static int check_render_args(rtw_ctx* c, const rtw_params* P) {
     return RTW_OK;
 }
 
-static size_t shard_rows(const rtw_params* P) {
+size_t shard_rows(const rtw_params* P) {
     const size_t k = P->row_stride > 1 ? (size_t)P->row_stride : 1;
     return ((size_t)(P->row1 - P->row0) + k - 1) / k;
 }
 
 // One device: the whole render of the shard P describes, result in d_rgba (device memory of c->device).
-static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, rtw_stats* stats) {
+int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, rtw_stats* stats) {
     HIP_TRY(c, hipSetDevice(c->device));
     if (!s) s = c->stream;
 
@@ -827,8 +903,14 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
     const unsigned pix_grid = (unsigned)std::min<size_t>((npix + kBlock - 1) / kBlock, (size_t)c->n_cu * 8);
     uint64_t launches = 0;
     const bool path_small = !c->sc.use_bvh && c->sc.n_prims <= kPathMaxPrims && (c->sc.n_walk_words > 0 || c->sc.has_tex);
+#ifdef RTW_EXPERIMENTS
     const bool path_tree = c->sc.use_bvh && tune.path_tree != 0;
-    const bool use_path = P->max_depth > 0 && tune.path != 0 && (path_small || path_tree);
+#else
+    const bool path_tree = false;  // (k_path_tree exists in -DRTW_EXPERIMENTS builds only: RTW_PATH_TREE is ignored here)
+#endif
+    // k_path packs a unit's pixel as x | y << 16: frames wider or taller than 65535 take the wavefront kernels
+    const bool fits16 = P->width <= 65535 && P->height <= 65535;
+    const bool use_path = P->max_depth > 0 && tune.path != 0 && fits16 && (path_small || path_tree);
 
     if (use_path) {
         // ---- k_path: paths in registers, lanes regenerate; only the unit sums (16 B per pixel and 64 samples) reach HBM
@@ -853,7 +935,10 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
                            : feat == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<R_, 1>, kBlock, path_lds) \
                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, K_<R_, 0>, kBlock, path_lds))
 #define RTW_OCC(K_) (lcg ? RTW_OCC_R(K_, RTW_RNG_TEA_LCG) : RTW_OCC_R(K_, RTW_RNG_PHILOX))
-            if (path_tree) qe = RTW_OCC(k_path_tree); else qe = RTW_OCC(k_path);
+#ifdef RTW_EXPERIMENTS
+            if (path_tree) qe = RTW_OCC(k_path_tree); else
+#endif
+            qe = RTW_OCC(k_path);
 #undef RTW_OCC
 #undef RTW_OCC_R
             wg_per_cu = (qe == hipSuccess && nb > 0) ? std::min(nb, 8) : 4;
@@ -966,7 +1051,11 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
         return ((chunks + g - 1) / g + 2) * (size_t)kBlock;
     };
     // RTW_PAIRED: batches run two at a time with their trace launches alternating (see the batch loop)
+#ifdef RTW_EXPERIMENTS
     const bool paired = tune.paired && n_lanes == 2 && c->sc.use_bvh;
+#else
+    const bool paired = false;  // (measured 12 % slower: -DRTW_EXPERIMENTS builds only)
+#endif
     // k_trace_bvh: large workgroups share one LDS copy of the tree (nodes, then leaf records) between more waves
     const int trace_block = tune.trace_block;
     int32_t trace_nodes = 0, trace_leaves = 0;
@@ -1190,9 +1279,9 @@ static int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStrea
 #endif
 #ifdef RTW_TRACE_COUNT
     {
-        unsigned long long w[6];
+        unsigned long long w[7];
         HIP_TRY_C(hipMemcpy(w, c->d_stats + kStatRows * 8, sizeof w, hipMemcpyDeviceToHost));
-        const double rays = (double)hs[2 + RTW_K_TRACE];
+        const double rays = (double)w[6];
         fprintf(stderr, "[rtw] k_trace_bvh: rays %.4g; per ray: node visits %.2f, primitive tests %.2f; wave steps per 64 rays: inner %.2f (lanes busy %.2f), leaf %.2f (lanes busy %.2f), outer %.2f\n",
                 rays, (double)hs[6] / rays, (double)hs[7] / rays, (double)w[0] * 64.0 / rays, (double)hs[6] / ((double)w[0] * 64.0), (double)w[1] * 64.0 / rays,
                 (double)hs[7] / ((double)w[1] * 64.0), (double)hs[2 + RTW_K_BOUNCE] * 64.0 / rays);
@@ -1236,44 +1325,61 @@ __global__ void __launch_bounds__(256) k_interleave(const float4* __restrict__ s
 }
 
 // n_devices > 1: kid g renders rows row0 + g*k, row0 + (g + n)*k ... of the shard (k = the caller's row stride) on its own
-// device and host thread; the float4 shards are then gathered on device_ids[0] with one hipMemcpyPeerAsync each
-// (single process: the peer copies are the xGMI transfers an RCCL send/recv pair would issue) and interleaved.
-static int render_group(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, rtw_stats* stats) {
+// device from its own (persistent) host thread and then PUSHES its float4 shard to device_ids[0] with one
+// hipMemcpyPeerAsync on its own stream - n concurrent transfers, one per inbound xGMI link of the gathering device (single
+// process: a peer copy is the xGMI transfer an RCCL send/recv pair would issue) - and the rows are interleaved there.
+int run_shard(rtw_ctx* kc, Worker& w) {
+    test_fault("worker");
+    if (hipSetDevice(kc->device) != hipSuccess) return fail(kc, RTW_ERR_DEVICE, "hipSetDevice failed");
+    if (w.npix == 0) return RTW_OK;
+    if (w.npix > kc->out_pix) {
+        if (kc->d_out) (void)hipFree(kc->d_out);
+        kc->d_out = nullptr; kc->out_pix = 0;
+        if (hipMalloc(&kc->d_out, w.npix * sizeof(float4)) != hipSuccess) return fail(kc, RTW_ERR_OOM, "shard buffer");
+        kc->out_pix = w.npix;
+    }
+    const int rc = render_single(kc, &w.P, kc->d_out, nullptr, w.want_stats ? &w.st : nullptr);
+    if (rc) return rc;
+    HIP_TRY(kc, hipMemcpyPeerAsync(w.gather_dst, w.gather_dev, kc->d_out, kc->device, w.npix * sizeof(float4), kc->stream));
+    HIP_TRY(kc, hipStreamSynchronize(kc->stream));
+    return RTW_OK;
+}
+void worker_main(rtw_ctx* kc) {
+    Worker& w = *kc->worker;
+    for (;;) {
+        try {
+            std::unique_lock<std::mutex> lk(w.m);
+            w.cv.wait(lk, [&] { return w.has_job || w.quit; });
+            if (w.quit) return;
+            lk.unlock();
+            int rc;
+            try {
+                rc = run_shard(kc, w);
+            } catch (const std::bad_alloc&) {
+                rc = fail_nothrow(kc, RTW_ERR_OOM, "out of host memory in a worker thread (std::bad_alloc)");
+            } catch (const std::exception& e) {
+                rc = fail_nothrow(kc, RTW_ERR_DEVICE, e.what());
+            } catch (...) {
+                rc = fail_nothrow(kc, RTW_ERR_DEVICE, "unknown exception in a worker thread");
+            }
+            lk.lock();
+            w.rc = rc; w.has_job = false; w.done = true;
+            lk.unlock();
+            w.cv.notify_all();
+        } catch (...) {
+            // a failing lock: nothing sane is left to do with this thread's queue; report once and leave
+            w.rc = RTW_ERR_DEVICE; w.has_job = false; w.done = true;
+            w.cv.notify_all();
+            return;
+        }
+    }
+}
+int render_group(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, rtw_stats* stats) {
     const size_t n = c->kids.size();
     const size_t k = P->row_stride > 1 ? (size_t)P->row_stride : 1;
     const size_t rows = shard_rows(P);
     if (stats) memset(stats, 0, sizeof *stats);
     if (rows == 0) return RTW_OK;
-    std::vector<rtw_params> kp(n, *P);
-    std::vector<size_t> krows(n, 0);
-    std::vector<uint32_t> off(n + 1, 0);
-    for (size_t g = 0; g < n; g++) {
-        kp[g].row0 = P->row0 + (int32_t)(g * k);
-        kp[g].row_stride = (int32_t)(k * n);
-        krows[g] = rows > g ? (rows - g + n - 1) / n : 0;
-        if (kp[g].row0 > kp[g].row1) kp[g].row0 = kp[g].row1;
-        off[g + 1] = off[g] + (uint32_t)krows[g];
-    }
-    std::vector<int> rcs(n, RTW_OK);
-    std::vector<rtw_stats> kst(n);
-    std::vector<std::thread> th;
-    for (size_t g = 0; g < n; g++) {
-        th.emplace_back([&, g]() {
-            rtw_ctx* kc = c->kids[g];
-            const size_t npix = krows[g] * (size_t)P->width;
-            if (hipSetDevice(kc->device) != hipSuccess) { rcs[g] = fail(kc, RTW_ERR_DEVICE, "hipSetDevice failed"); return; }
-            if (npix > kc->out_pix) {
-                if (kc->d_out) (void)hipFree(kc->d_out);
-                kc->d_out = nullptr; kc->out_pix = 0;
-                if (hipMalloc(&kc->d_out, std::max<size_t>(npix, 1) * sizeof(float4)) != hipSuccess) { rcs[g] = fail(kc, RTW_ERR_OOM, "shard buffer"); return; }
-                kc->out_pix = npix;
-            }
-            rcs[g] = npix ? render_single(kc, &kp[g], kc->d_out, nullptr, &kst[g]) : RTW_OK;
-        });
-    }
-    for (auto& t : th) t.join();
-    for (size_t g = 0; g < n; g++)
-        if (rcs[g] != RTW_OK) return fail(c, rcs[g], std::string("device ") + std::to_string(c->kids[g]->device) + ": " + c->kids[g]->err);
     HIP_TRY(c, hipSetDevice(c->device));
     if (!s) s = c->stream;
     const size_t npix = rows * (size_t)P->width;
@@ -1283,32 +1389,62 @@ static int render_group(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream
         HIP_TRY(c, hipMalloc(&c->stage, npix * sizeof(float4) + (n + 1) * sizeof(uint32_t) + 256));
         c->stage_pix = npix;
     }
+    std::vector<uint32_t> off(n + 1, 0);
+    std::vector<size_t> krows(n, 0);
+    for (size_t g = 0; g < n; g++) {
+        krows[g] = rows > g ? (rows - g + n - 1) / n : 0;
+        off[g + 1] = off[g] + (uint32_t)krows[g];
+    }
+    // hand every kid its shard, then wait for all of them (a failing or throwing kid reports through its rc)
+    for (size_t g = 0; g < n; g++) {
+        Worker& w = *c->kids[g]->worker;
+        std::lock_guard<std::mutex> lk(w.m);
+        w.P = *P;
+        w.P.row0 = P->row0 + (int32_t)(g * k);
+        w.P.row_stride = (int32_t)(k * n);
+        if (w.P.row0 > w.P.row1) w.P.row0 = w.P.row1;
+        w.npix = krows[g] * (size_t)P->width;
+        w.gather_dst = c->stage + (size_t)off[g] * P->width;
+        w.gather_dev = c->device;
+        w.want_stats = stats != nullptr;
+        memset(&w.st, 0, sizeof w.st);
+        w.rc = RTW_OK; w.done = false; w.has_job = true;
+    }
+    for (size_t g = 0; g < n; g++) c->kids[g]->worker->cv.notify_all();
+    int first_rc = RTW_OK;
+    size_t first_bad = 0;
+    for (size_t g = 0; g < n; g++) {
+        Worker& w = *c->kids[g]->worker;
+        std::unique_lock<std::mutex> lk(w.m);
+        w.cv.wait(lk, [&] { return w.done; });
+        if (w.rc != RTW_OK && first_rc == RTW_OK) { first_rc = w.rc; first_bad = g; }
+    }
+    if (first_rc != RTW_OK)
+        return fail(c, first_rc, std::string("device ") + std::to_string(c->kids[first_bad]->device) + ": " + c->kids[first_bad]->err);
+    HIP_TRY(c, hipSetDevice(c->device));
     uint32_t* d_off = (uint32_t*)((char*)c->stage + ((npix * sizeof(float4) + 255) & ~(size_t)255));
     HIP_TRY(c, hipMemcpyAsync(d_off, off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    for (size_t g = 0; g < n; g++) {  // the gather: one peer copy per shard, all on the group's stream
-        const size_t bytes = krows[g] * (size_t)P->width * sizeof(float4);
-        if (bytes) HIP_TRY(c, hipMemcpyPeerAsync(c->stage + (size_t)off[g] * P->width, c->device, c->kids[g]->d_out, c->kids[g]->device, bytes, s));
-    }
     hipLaunchKernelGGL(k_interleave, dim3((unsigned)std::min<size_t>((npix + 255) / 256, (size_t)c->n_cu * 8)), dim3(256), 0, s, (const float4*)c->stage,
                        (float4*)d_rgba, (uint32_t)P->width, (uint32_t)rows, (uint32_t)n, (const uint32_t*)d_off);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(s));
     if (stats) {
         for (size_t g = 0; g < n; g++) {
-            stats->samples += kst[g].samples; stats->segments += kst[g].segments; stats->shadow_rays += kst[g].shadow_rays;
-            stats->algorithmic_bytes += kst[g].algorithmic_bytes; stats->bounce_launches += kst[g].bounce_launches;
-            stats->seconds = std::max(stats->seconds, kst[g].seconds);
-            stats->bounce_seconds = std::max(stats->bounce_seconds, kst[g].bounce_seconds);
+            const rtw_stats& ks = c->kids[g]->worker->st;
+            stats->samples += ks.samples; stats->segments += ks.segments; stats->shadow_rays += ks.shadow_rays;
+            stats->algorithmic_bytes += ks.algorithmic_bytes; stats->bounce_launches += ks.bounce_launches;
+            stats->seconds = std::max(stats->seconds, ks.seconds);
+            stats->bounce_seconds = std::max(stats->bounce_seconds, ks.bounce_seconds);
             for (int q = 0; q < RTW_K_COUNT; q++) {
-                stats->kernel_seconds[q] += kst[g].kernel_seconds[q]; stats->kernel_launches[q] += kst[g].kernel_launches[q];
-                stats->kernel_segments[q] += kst[g].kernel_segments[q];
+                stats->kernel_seconds[q] += ks.kernel_seconds[q]; stats->kernel_launches[q] += ks.kernel_launches[q];
+                stats->kernel_segments[q] += ks.kernel_segments[q];
             }
         }
     }
     return RTW_OK;
 }
 
-int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_stream, rtw_stats* stats) {
+int impl_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_stream, rtw_stats* stats) {
     if (!c) return RTW_ERR_INVALID_ARG;
     int rc = check_render_args(c, P);
     if (rc) return rc;
@@ -1317,7 +1453,7 @@ int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_s
     return render_single(c, P, d_rgba, (hipStream_t)hip_stream, stats);
 }
 
-int rtw_render(rtw_ctx* c, const rtw_params* P, float* rgba_out, rtw_stats* stats) {
+int impl_render(rtw_ctx* c, const rtw_params* P, float* rgba_out, rtw_stats* stats) {
     if (!c) return RTW_ERR_INVALID_ARG;
     if (!rgba_out) return fail(c, RTW_ERR_INVALID_ARG, "null output");
     if (!P) return fail(c, RTW_ERR_INVALID_ARG, "null params");
@@ -1330,13 +1466,13 @@ int rtw_render(rtw_ctx* c, const rtw_params* P, float* rgba_out, rtw_stats* stat
         HIP_TRY(c, hipMalloc(&c->d_out, std::max<size_t>(npix, 1) * sizeof(float4)));
         c->out_pix = npix;
     }
-    int rc = rtw_render_device(c, P, c->d_out, nullptr, stats);
+    int rc = impl_render_device(c, P, c->d_out, nullptr, stats);
     if (rc) return rc;
     if (npix) HIP_TRY(c, hipMemcpy(rgba_out, c->d_out, npix * sizeof(float4), hipMemcpyDeviceToHost));  // Director.cpp:999-1000
     return RTW_OK;
 }
 
-int rtw_denoise(rtw_ctx* c, const float* rgba_in, float* rgba_out, int32_t width, int32_t height, int32_t iterations, float sigma) {
+int impl_denoise(rtw_ctx* c, const float* rgba_in, float* rgba_out, int32_t width, int32_t height, int32_t iterations, float sigma) {
     if (!c) return RTW_ERR_INVALID_ARG;
     if (!rgba_in || !rgba_out || rgba_in == rgba_out || width <= 0 || height <= 0 || iterations < 1 || iterations > 8 || !(sigma > 0.f) ||
         (int64_t)width * height > (1 << 28))
@@ -1366,7 +1502,7 @@ int rtw_denoise(rtw_ctx* c, const float* rgba_in, float* rgba_out, int32_t width
     return RTW_OK;
 }
 
-int rtw_debug_intersect(rtw_ctx* c, const float* rays, const float* ray_time, const float* gather_time, int n, float* out_t, int32_t* out_prim) {
+int impl_debug_intersect(rtw_ctx* c, const float* rays, const float* ray_time, const float* gather_time, int n, float* out_t, int32_t* out_prim) {
     if (!c) return RTW_ERR_INVALID_ARG;
     if (!c->has_scene) return fail(c, RTW_ERR_NO_SCENE, "no scene");
     if (n < 0 || (n > 0 && (!rays || !out_t || !out_prim))) return fail(c, RTW_ERR_INVALID_ARG, "bad arguments");
@@ -1396,6 +1532,32 @@ int rtw_debug_intersect(rtw_ctx* c, const float* rays, const float* ray_time, co
     cleanup();
 #undef HIP_TRY_D
     return RTW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rtw_abi_version(void) { return RTW_ABI_VERSION; }
+
+const char* rtw_last_error(rtw_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids) {
+    if (!out) return RTW_ERR_INVALID_ARG;
+    *out = nullptr;
+    return guarded(nullptr, [&] { return impl_create(out, n_devices, device_ids); });
+}
+int rtw_destroy(rtw_ctx* c) { return guarded(nullptr, [&] { return impl_destroy(c); }); }
+int rtw_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) { return guarded(c, [&] { return impl_upload_scene(c, blob, bytes); }); }
+int rtw_render_device(rtw_ctx* c, const rtw_params* P, void* d_rgba, void* hip_stream, rtw_stats* stats) {
+    return guarded(c, [&] { return impl_render_device(c, P, d_rgba, hip_stream, stats); });
+}
+int rtw_render(rtw_ctx* c, const rtw_params* P, float* rgba_out, rtw_stats* stats) { return guarded(c, [&] { return impl_render(c, P, rgba_out, stats); }); }
+int rtw_denoise(rtw_ctx* c, const float* rgba_in, float* rgba_out, int32_t width, int32_t height, int32_t iterations, float sigma) {
+    return guarded(c, [&] { return impl_denoise(c, rgba_in, rgba_out, width, height, iterations, sigma); });
+}
+int rtw_debug_intersect(rtw_ctx* c, const float* rays, const float* ray_time, const float* gather_time, int n, float* out_t, int32_t* out_prim) {
+    return guarded(c, [&] { return impl_debug_intersect(c, rays, ray_time, gather_time, n, out_t, out_prim); });
 }
 
 }  // extern "C"

@@ -2,7 +2,7 @@
 //
 //   k_path       small scenes: whole paths in registers, lanes own (pixel, sample block) units and regenerate; LDS candidate
 //                lists and hit records; only 16-byte unit sums reach HBM
-//   k_path_tree  the same for tree scenes, lanes vote on the kind of step (built, slower than the wavefront kernels, off)
+//   k_path_tree  the same for tree scenes, lanes vote on the kind of step (slower than the wavefront kernels: -DRTW_EXPERIMENTS builds only)
 //   k_first      generate primary rays (raygen.cu:123-147, camera.cu:11-19), trace and shade the primary segment
 //   k_shade      closest-hit / miss programs for one bounce of every live path: (media: the volume pass), material
 //                scatter, texture, light sampling (the shadow ray is QUEUED in the path state, not traced), Russian
@@ -638,7 +638,7 @@ RTW_DEV void trace_path(const KArgs& A, const Path& p, size_t slot, const TravMe
             occl = (sprim >= 0 ? 0x80000000u : 0u) | 0x40000000u;
         }
     }
-    n_rays += (do_r ? 1u : 0u) + (do_s ? 1u : 0u);
+    n_rays += (do_r || do_s) ? 1u : 0u;  // unit of the trace kernels: one path slot (its radiance ray and its queued probe)
     A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1) | occl);
 }
 
@@ -661,7 +661,10 @@ RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const ui
     float r0, r1, r2, r3, r4;
     if (KIND == RTW_RNG_TEA_LCG) {
         uint32_t s = tea<64>(pixel, sample);  // raygen.cu:129
-        r0 = lcg_rnd(s); r1 = lcg_rnd(s); r2 = lcg_rnd(s); r3 = lcg_rnd(s);
+        r0 = lcg_rnd(s); r1 = lcg_rnd(s);
+        r2 = 0.0f; r3 = 0.0f;
+        // camera.cu:11-19: the perspective camera draws its lens sample (used or not); scene/camera.cuh:35-56: the other two take no seed
+        if (LDS_CAM || A.sc.cam_type == RTW_CAM_PERSPECTIVE) { r2 = lcg_rnd(s); r3 = lcg_rnd(s); }
         g.init(A.seed, pixel, sample, s, s);  // prd.seed = seed; rayColor's local copy (Q7)
         r4 = lcg_rnd(s);
         p.w0 = path_id;
@@ -879,7 +882,7 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
     bool shadow_phase = false;
     const uint32_t root = A.sc.n_tree > 0 ? 0u : kBvhDone;
 #ifdef RTW_TRACE_COUNT
-    uint32_t c_inner = 0, c_prim = 0, c_outer = 0, c_winner = 0, c_wleaf = 0;
+    uint32_t c_inner = 0, c_prim = 0, c_outer = 0, c_winner = 0, c_wleaf = 0, c_rays = 0;
     // wave cycles by part of the loop: 0 refill, 1 inner steps, 2 leaf step, 3 finished rays
     unsigned long long tc[4] = {0, 0, 0, 0}, tc_t0 = __builtin_amdgcn_s_memtime();
 #define RTW_TC(I_) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); tc[I_] += now_ - tc_t0; tc_t0 = now_; }
@@ -924,7 +927,10 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
                     inv = recip3(d);
                     best_prim = -1; sp = 0; cur = root; pend = 0u;
                     if (do_r || ltmax >= 0.0f) {
-                        n_rays++;
+                        n_rays++;  // the kernel's unit: one path slot (radiance ray + queued probe)
+#ifdef RTW_TRACE_COUNT
+                        c_rays++;
+#endif
                         active = true;
                     } else {
                         A.hit_out[slot] = make_uint2(0u, 0u);  // a zombie without a probe (does not occur; kept total)
@@ -1005,7 +1011,9 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
                     if (ltmax >= 0.0f) {  // traceOcclusion, closehit.cu:16-42 (ray time 0)
                         d = ldir; inv = recip3(d); tmin = A.sc.probe_eps; best_t = ltmax; ray_time = 0.0f;
                         best_prim = -1; sp = 0; cur = root; shadow_phase = true;
-                        n_rays++;
+#ifdef RTW_TRACE_COUNT
+                        c_rays++;
+#endif
                     } else {
                         A.hit_out[slot] = make_uint2(__float_as_uint(th), (uint32_t)(prim + 1));
                         active = false;
@@ -1019,10 +1027,10 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
         }
     }
 #ifdef RTW_TRACE_COUNT
-    for (int off = 32; off > 0; off >>= 1) { c_inner += __shfl_down(c_inner, off); c_prim += __shfl_down(c_prim, off); }
+    for (int off = 32; off > 0; off >>= 1) { c_inner += __shfl_down(c_inner, off); c_prim += __shfl_down(c_prim, off); c_rays += __shfl_down(c_rays, off); }
     RTW_TC(3)
     if ((tid & 63u) == 0) for (int q = 0; q < 4; q++) atomicAdd(&A.stats[kStatRows * 8 + 2 + q], tc[q]);
-    if ((tid & 63u) == 0) { atomicAdd(&A.stats[kStatRows * 8 + 0], (unsigned long long)c_winner); atomicAdd(&A.stats[kStatRows * 8 + 1], (unsigned long long)c_wleaf); atomicAdd(&A.stats[6], (unsigned long long)c_inner); atomicAdd(&A.stats[7], (unsigned long long)c_prim); atomicAdd(&A.stats[2 + RTW_K_BOUNCE], (unsigned long long)c_outer); }
+    if ((tid & 63u) == 0) { atomicAdd(&A.stats[kStatRows * 8 + 0], (unsigned long long)c_winner); atomicAdd(&A.stats[kStatRows * 8 + 1], (unsigned long long)c_wleaf); atomicAdd(&A.stats[6], (unsigned long long)c_inner); atomicAdd(&A.stats[7], (unsigned long long)c_prim); atomicAdd(&A.stats[2 + RTW_K_BOUNCE], (unsigned long long)c_outer); atomicAdd(&A.stats[kStatRows * 8 + 6], (unsigned long long)c_rays); }
 #endif
 #undef RTW_TC
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off);
@@ -1036,7 +1044,8 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
 // RTW_SHADE_SORT=1 (experiment, off): deal a chunk's paths to the threads by hit material. Measured: k_shade 4-7 % SLOWER on
 // scenes 1, 2, 4 with one lane or two - the kernel moves 170-185 B per segment at the HBM copy rate, its serialised material
 // branches hide behind that, and the sort adds a dependent load (hit record -> material) in front of the path loads.
-#ifndef RTW_SHADE_SORT
+#if !defined(RTW_SHADE_SORT) || !defined(RTW_EXPERIMENTS)
+#undef RTW_SHADE_SORT
 #define RTW_SHADE_SORT 0
 #endif
 template <int KIND, int TEX>
@@ -1487,6 +1496,7 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
     }
 }
 
+#ifdef RTW_EXPERIMENTS  // measured slower than the default paths: built by scripts/build_variant.sh only, never by build()
 // ------------------------------------------------------------------ k_path_tree
 // Tree scenes, same idea as k_path (paths in registers, lanes own units of one pixel x one sample block and regenerate,
 // only the unit sums reach HBM), but a ray's walk through the BVH takes a different number of steps in every lane, so a
@@ -1749,6 +1759,8 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
         if (n_shadow) atomicAdd(&row[1], (unsigned long long)n_shadow);
     }
 }
+
+#endif  // RTW_EXPERIMENTS
 
 // per-pixel sums, block by block in ascending order (the arithmetic spec's summation order: samples are summed in
 // order inside aligned blocks of kSumBlock, the block sums in order)

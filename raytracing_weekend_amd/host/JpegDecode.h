@@ -98,6 +98,7 @@ private:
     // entropy decoder state
     uint32_t bits_ = 0;
     int nbits_ = 0;
+    int pad_bits_ = 0;  // bits at the tail of the buffer that did not come from the file (fed after its end or after a marker)
     bool hit_marker_ = false;
 
     static bool fail(std::string& err, const char* msg) { err = msg; return false; }
@@ -158,12 +159,17 @@ private:
             if (k.v > vmax_) vmax_ = k.v;
         }
         const int mcux = (w_ + 8 * hmax_ - 1) / (8 * hmax_), mcuy = (h_ + 8 * vmax_ - 1) / (8 * vmax_);
+        // A coded 8x8 block takes at least two bits (a DC and an end-of-block code of one bit each), so a file of n bytes
+        // cannot describe more than 4 n blocks: a header that declares more is refused before anything is allocated for it
+        size_t blocks = 0;
         for (int c = 0; c < ncomp_; c++) {
             Component& k = comp_[c];
             if (hmax_ % k.h || vmax_ % k.v) return fail(err, "fractional sampling ratios are not supported");
             k.bw = mcux * k.h; k.bh = mcuy * k.v;
-            k.plane.assign(static_cast<size_t>(k.bw) * 8 * k.bh * 8, 0);
+            blocks += static_cast<size_t>(k.bw) * k.bh;
         }
+        if (blocks > 4 * n_) return fail(err, "JPEG header declares more blocks than the file can hold");
+        for (int c = 0; c < ncomp_; c++) comp_[c].plane.assign(static_cast<size_t>(comp_[c].bw) * 8 * comp_[c].bh * 8, 0);
         return true;
     }
     bool readSOS(const uint8_t* s, size_t n, std::string& err) {
@@ -182,14 +188,17 @@ private:
     void fillBits() {
         while (nbits_ <= 24) {
             int b = 0;
+            bool real = false;
             if (!hit_marker_ && pos_ < n_) {
                 b = d_[pos_];
+                real = true;
                 if (b == 0xFF) {
                     const int b2 = pos_ + 1 < n_ ? d_[pos_ + 1] : 0xD9;
                     if (b2 == 0) pos_ += 2;              // stuffed zero
-                    else { hit_marker_ = true; b = 0; }  // a marker: feed zeros until the caller deals with it
+                    else { hit_marker_ = true; b = 0; real = false; }  // a marker: zeros from here on
                 } else pos_++;
             }
+            if (!real) pad_bits_ += 8;  // not from the file; a valid stream never consumes these (decodeBlock checks)
             bits_ |= static_cast<uint32_t>(b) << (24 - nbits_);
             nbits_ += 8;
         }
@@ -218,6 +227,7 @@ private:
         const int t = decodeSymbol(dc_[k.td]);
         if (t < 0 || t > 11) return false;
         k.pred += extend(getBits(t), t);
+        if (k.pred < -16384 || k.pred > 16384) return false;  // 8-bit samples keep the quantised DC within +-2048
         coef[0] = k.pred * qt_[k.tq][0];
         for (int i = 1; i < 64;) {
             const int rs = decodeSymbol(ac_[k.ta]);
@@ -228,21 +238,23 @@ private:
                 break;  // end of block
             }
             i += r;
-            if (i > 63) return false;
+            if (i > 63 || s > 10) return false;  // (8-bit samples: AC magnitude categories 1..10, T.81 F.1.2.2)
             coef[zz[i]] = extend(getBits(s), s) * qt_[k.tq][zz[i]];
             i++;
         }
-        return true;
+        return nbits_ >= pad_bits_;  // false: the block consumed bits the file does not hold (truncated or a marker inside the data)
     }
     static void idct(const int coef[64], uint8_t* out, int stride) {
         // s(y,x) = 1/4 sum_u sum_v C(u) C(v) S(v,u) cos((2x+1)u pi/16) cos((2y+1)v pi/16) + 128   (T.81 A.3.3)
-        static double basis[8][8];
-        static bool init = false;
-        if (!init) {
-            for (int x = 0; x < 8; x++)
-                for (int u = 0; u < 8; u++) basis[x][u] = (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0) * 0.5;
-            init = true;
-        }
+        struct Basis {  // function-local static with a constructor: initialised once, thread-safe (two scenes may load at once)
+            double b[8][8];
+            Basis() {
+                for (int x = 0; x < 8; x++)
+                    for (int u = 0; u < 8; u++) b[x][u] = (u == 0 ? std::sqrt(0.5) : 1.0) * std::cos((2 * x + 1) * u * 3.14159265358979323846 / 16.0) * 0.5;
+            }
+        };
+        static const Basis table;
+        const double (*basis)[8] = table.b;
         double tmp[64];
         for (int v = 0; v < 8; v++)
             for (int x = 0; x < 8; x++) {
@@ -260,14 +272,14 @@ private:
     }
     bool decodeScan(std::string& err) {
         const int mcux = comp_[0].bw / comp_[0].h, mcuy = comp_[0].bh / comp_[0].v;
-        bits_ = 0; nbits_ = 0; hit_marker_ = false;
+        bits_ = 0; nbits_ = 0; pad_bits_ = 0; hit_marker_ = false;
         int until_restart = restart_;
         int coef[64];
         for (int my = 0; my < mcuy; my++)
             for (int mx = 0; mx < mcux; mx++) {
                 if (restart_ && until_restart == 0) {
                     // byte-align, expect RSTn, reset the predictors (T.81 F.2.1.3.1 / E.2.4)
-                    bits_ = 0; nbits_ = 0; hit_marker_ = false;
+                    bits_ = 0; nbits_ = 0; pad_bits_ = 0; hit_marker_ = false;
                     const int m = nextMarker();
                     if (m < 0xD0 || m > 0xD7) return fail(err, "missing restart marker");
                     for (int c = 0; c < ncomp_; c++) comp_[c].pred = 0;
@@ -277,7 +289,7 @@ private:
                     Component& k = comp_[c];
                     for (int by = 0; by < k.v; by++)
                         for (int bx = 0; bx < k.h; bx++) {
-                            if (!decodeBlock(k, coef)) return fail(err, "corrupt entropy-coded data");
+                            if (!decodeBlock(k, coef)) return fail(err, "corrupt or truncated entropy-coded data");
                             const int stride = k.bw * 8;
                             idct(coef, k.plane.data() + static_cast<size_t>(my * k.v + by) * 8 * stride + static_cast<size_t>(mx * k.h + bx) * 8, stride);
                         }

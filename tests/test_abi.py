@@ -39,6 +39,37 @@ def test_null_context_is_an_error_not_a_crash():
     assert lib.rtw_last_error(None) is not None
 
 
+def test_no_exception_crosses_the_c_abi(monkeypatch):
+    """include/rtw.h promises error codes, not exceptions. RTW_TEST_FAULT=entry:<kind> makes every entry point
+    throw inside its guard before it looks at its arguments: a std::bad_alloc must come back as RTW_ERR_OOM, anything else
+    as RTW_ERR_DEVICE, and the process must live (without the barrier std::terminate ends it). The in-thread and
+    mid-upload injection points need a GPU: tests/test_gpu_round3.py."""
+    lib = abi.load_hip()
+    ctx = C.c_void_p()
+    p = abi.make_params(8, 8, 1, 2)
+    out = (C.c_float * 256)()
+    for kind, want in (("bad_alloc", -5), ("runtime", -4)):
+        monkeypatch.setenv("RTW_TEST_FAULT", "entry:" + kind)
+        assert lib.rtw_create(C.byref(ctx), 1, None) == want and not ctx.value
+        assert lib.rtw_upload_scene(None, b"x", 1) == want
+        assert lib.rtw_render(None, C.byref(p), out, None) == want
+        assert lib.rtw_render_device(None, C.byref(p), None, None, None) == want
+        assert lib.rtw_denoise(None, None, None, 1, 1, 1, 1.0) == want
+        assert lib.rtw_debug_intersect(None, None, None, None, 0, None, None) == want
+        assert lib.rtw_destroy(None) == want
+    monkeypatch.delenv("RTW_TEST_FAULT")
+    assert lib.rtw_destroy(None) == -1  # back to the plain argument check
+    # every extern "C" definition in the library's source runs inside the guard
+    src = open(os.path.join(abi.PKG_DIR, "csrc", "rtw_hip.hip")).read()
+    ext = src[src.index('extern "C" {'):]
+    for name in declared_functions():
+        body = ext[ext.index(name + "("):]
+        body = body[:body.index("\n}") + 2] if "{" in body.split("\n")[0] else body
+        if name in ("rtw_abi_version", "rtw_last_error"):
+            continue  # no allocation, nothing to throw
+        assert "guarded(" in body.split("\n}")[0], name
+
+
 def test_product_package_does_not_reference_the_oracle():
     pkg = os.path.join(abi.REPO_DIR, "raytracing_weekend_amd")
     for root, _, files in os.walk(pkg):

@@ -199,7 +199,7 @@ def test_textured_scene_through_the_fused_path(gpu):
 
 def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
     """Pipeline (k_path with paths in registers vs the wavefront kernels), lanes, pool size, tail start, fused vs split
-    (with and without media), LDS budget, grid size, k_first's sample grouping, the trace kernel's workgroup size and LDS image, the paired batch schedule,
+    (with and without media), LDS budget, grid size, k_first's sample grouping, the trace kernel's workgroup size and LDS image,
     job and unit size, the fine-grained end-game launch, block-sum passes:
     tuning knobs move work between kernels, lanes and streams, never a bit of the image or a count."""
     cases = [(abi.build_scene(0, 96, 64), 96, 64, 150, 30), (abi.build_scene(3, 64, 64), 64, 64, 10, 30),
@@ -210,13 +210,12 @@ def test_image_does_not_depend_on_the_launch_schedule(gpu, monkeypatch):
             {"RTW_LDS_KB": "48", "RTW_BRUTE_MAX": "0"}, {"RTW_POOL_PATHS": "4096", "RTW_GRID_MULT": "3"},
             {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "0"}, {"RTW_POOL_PATHS": "30000", "RTW_STAGGER": "30"},
             {"RTW_FIRST_GROUP_LOG2": "0"}, {"RTW_FIRST_GROUP_LOG2": "6", "RTW_POOL_PATHS": "200000"},
-            {"RTW_TRACE_BLOCK": "512", "RTW_TRACE_LDS_KB": "40"}, {"RTW_TRACE_WAVES": "3", "RTW_TRACE_LDS_KB": "5"},
-            {"RTW_PAIRED": "1", "RTW_POOL_PATHS": "30000"}, {"RTW_PAIRED": "1", "RTW_PAIRED_TRACE_WAVES": "6", "RTW_POOL_PATHS": "9000"}]
-    knobs = [{}, {"RTW_PATH_TREE": "1"}, {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_PATH_JOB_BLOCKS": "1", "RTW_PATH_GRID_MULT": "1"},
+            {"RTW_TRACE_BLOCK": "512", "RTW_TRACE_LDS_KB": "40"}, {"RTW_TRACE_WAVES": "3", "RTW_TRACE_LDS_KB": "5"}]
+    # (k_path_tree and the paired schedule left the product library in round 3: tests/test_gpu_round3.py keeps one variant test)
+    knobs = [{}, {"RTW_BRUTE_MAX": "0", "RTW_PATH_JOB_BLOCKS": "1", "RTW_PATH_GRID_MULT": "1"},
              {"RTW_PATH_JOB_BLOCKS": "7", "RTW_BLOCKSUM_BYTES": "65536"}, {"RTW_PATH_GRID_MULT": "2", "RTW_KERNEL_TIMING": "0"},
-             {"RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0", "RTW_LDS_KB": "0"}, {"RTW_PATH_TREE": "1", "RTW_LDS_KB": "40"},
              {"RTW_PATH_FINE_BLOCKS": "1", "RTW_PATH_UNIT_BLOCKS": "3"}, {"RTW_PATH_FINE_BLOCKS": "0", "RTW_PATH_UNIT_BLOCKS": "4"},
-             {"RTW_PATH_FINE_BLOCKS": "2", "RTW_PATH_UNIT_BLOCKS": "7", "RTW_PATH_TREE": "1", "RTW_BRUTE_MAX": "0"}]
+             {"RTW_PATH_FINE_BLOCKS": "2", "RTW_PATH_UNIT_BLOCKS": "7"}]
     knobs += [dict(k, RTW_PATH="0") for k in wave]
     names = sorted({k for kn in knobs for k in kn})
     for blob, w, h, spp, depth in cases:
@@ -489,7 +488,7 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert d["config"]["segments_per_sample"] > 1.0
-    assert d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["frac"] < 1
 
 
 def test_bench_rccl_path_at_world_size_one():

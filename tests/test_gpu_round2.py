@@ -226,11 +226,11 @@ def test_group_context_errors():
     assert lib.rtw_destroy(ctx) == 0
 
 
-@pytest.mark.parametrize("env", [{}, {"RTW_PATH_TREE": "1"}, {"RTW_LANES": "1", "RTW_TAIL_START": "2"}])
+@pytest.mark.parametrize("env", [{}, {"RTW_LANES": "1", "RTW_TAIL_START": "2"}])
 def test_tree_beyond_16_bit_references(gpu, monkeypatch, env):
     """9 000 primitives (moving spheres among them, lights, sky): the leaf table has more slots than a 16-bit stack entry
     can name, so the walk takes its 32-bit form (k_trace_bvh mode 0, the step with branches) - a form no reference scene
-    reaches. Wavefront kernels, k_path_tree, and the fused tail from depth 2 (traverse<>)."""
+    reaches. Wavefront kernels, and the fused tail from depth 2 (traverse<>)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     W, H = 48, 36

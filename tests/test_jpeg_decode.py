@@ -97,6 +97,30 @@ def test_unsupported_and_corrupt_files_are_refused():
             pass
 
 
+def test_truncated_scan_and_header_bombs_are_refused():
+    """a scan that ends early must fail (not decode zeros to the end), and a header that declares more blocks than
+    the file could hold must be refused before any plane is allocated."""
+    import struct
+    src = picture(96, 80, 3)
+    buf = io.BytesIO()
+    PIL.fromarray(src).save(buf, format="JPEG", quality=90, subsampling=0)
+    good = buf.getvalue()
+    sos = good.index(b"\xff\xda")
+    for cut in (sos + 20, sos + (len(good) - sos) // 2, len(good) - 40):
+        with pytest.raises(ValueError, match="truncated"):
+            decode(good[:cut])
+    # the entropy-coded data cut in the middle but with the EOI marker kept: a marker inside the data
+    with pytest.raises(ValueError, match="truncated"):
+        decode(good[:sos + (len(good) - sos) // 2] + b"\xff\xd9")
+    # header bomb: the same file claiming 32768 x 32768 pixels (3 GB of planes before the fix)
+    sof = good.index(b"\xff\xc0")
+    bomb = bytearray(good)
+    bomb[sof + 5:sof + 9] = struct.pack(">HH", 32768, 32768)
+    with pytest.raises(ValueError, match="more blocks than the file"):
+        decode(bytes(bomb))
+    assert decode(good).shape == (80, 96, 3)
+
+
 def test_reference_asset_decodes_like_pillow():
     path = "/root/reference/RestOfLife/assets/earthmap.jpg"
     if not os.path.exists(path):
