@@ -2,7 +2,7 @@
 # usage: scripts/isa_phases.sh [extra flags] : static instruction counts of k_path<PHILOX,false> per phase (between the phase-fence comments)
 R=$(cd "$(dirname "$0")/.." && pwd)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DRTW_MIN_WAVES=4 "$@" -S --cuda-device-only -o /tmp/rtw.s $R/raytracing_weekend_amd/csrc/rtw_hip.hip 2>&1 | grep -E "error" 
-awk '/^_ZN4rtwk6k_pathILi0ELb0EEEvNS_5KArgsE:/{f=1} f{print} /s_endpgm/{if(f){exit}}' /tmp/rtw.s > /tmp/kpath.s
+awk '/^_ZN4rtwk6k_pathILi0ELi0EEEvNS_5KArgsE:/{f=1} f{print} /s_endpgm/{if(f){exit}}' /tmp/rtw.s > /tmp/kpath.s
 python3 - <<'PY'
 import re,collections
 cur="pre"; cnt=collections.OrderedDict()
