@@ -37,12 +37,17 @@ extern "C" {
 #define RTW_ABI_VERSION 2   /* entry points and the structs they take (rtw_params, rtw_stats) */
 #define RTW_SCENE_VERSION 1 /* layout of the scene blob (rtw_scene_header.version) */
 #define RTW_SCENE_MAGIC 0x57545221u /* "!RTW" */
-/* Summation order of a pixel's samples (part of the arithmetic contract): the samples of a render call are
- * summed in ascending order inside aligned blocks of RTW_SUM_BLOCK samples (counted from sample_offset), and the block
- * sums are added in ascending order; the mean is that sum divided by spp. The reference renders one sample per launch
- * (raygen.cu:123-159) and so defines no order; blocks let a lane own a run of a pixel's samples in registers, and a small
- * block lets the last few percent of a render be handed out in short pieces (a launch ends when its slowest piece ends). */
+/* Summation order of a pixel's samples (part of the arithmetic contract). Three levels, all counted from
+ * sample_offset: the samples of a render call are summed in ascending order inside aligned BLOCKS of RTW_SUM_BLOCK samples;
+ * the block sums in ascending order inside aligned UNITS of RTW_SUM_UNIT_BLOCKS blocks (128 samples); the unit sums in
+ * ascending order; the mean is that sum divided by spp. The reference renders one sample per launch (raygen.cu:123-159) and
+ * so defines no order. Blocks let a lane own a run of a pixel's samples in registers, and a small block lets the last few
+ * percent of a render be handed out in short pieces (a launch ends when its slowest piece ends); units are what a lane of a
+ * long render owns at a time, so that one 16-byte sum per 128 samples reaches memory instead of one per 16 (round 3: the
+ * metric frame's sums take 1.3 GB instead of 8.5 GB, BASELINE config 5's shard 2.6 GB instead of 17 GB in two passes).
+ * Renders of at most 128 spp are unchanged by the unit level (0 + x = x). */
 #define RTW_SUM_BLOCK 16
+#define RTW_SUM_UNIT_BLOCKS 8
 
 typedef enum rtw_status {
     RTW_OK = 0,

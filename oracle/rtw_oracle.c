@@ -1130,16 +1130,23 @@ static void render_rows(const scene_t* sc, const rtw_params* P, int l0, int l1, 
     for (int l = l0; l < l1; l++) {
         int y = P->row0 + l * k;
         for (int x = 0; x < W; x++) {
-            /* summation order of include/rtw.h RTW_SUM_BLOCK: in order inside aligned blocks, then the block sums in order */
+            /* summation order of include/rtw.h (RTW_SUM_BLOCK, RTW_SUM_UNIT_BLOCKS): samples in order inside aligned blocks, the
+             * block sums in order inside aligned units of blocks, the unit sums in order */
             v3 sum = V(0.f, 0.f, 0.f);
-            for (int s0 = 0; s0 < P->spp; s0 += RTW_SUM_BLOCK) {
-                v3 bsum = V(0.f, 0.f, 0.f);
-                const int s1 = s0 + RTW_SUM_BLOCK < P->spp ? s0 + RTW_SUM_BLOCK : P->spp;
-                for (int s = s0; s < s1; s++) {
-                    v3 L = trace_path(sc, P, x, y, P->sample_offset + s, cn);
-                    bsum = vadd(bsum, L);
+            const int unit = RTW_SUM_BLOCK * RTW_SUM_UNIT_BLOCKS;
+            for (int u0 = 0; u0 < P->spp; u0 += unit) {
+                v3 usum = V(0.f, 0.f, 0.f);
+                const int u1 = u0 + unit < P->spp ? u0 + unit : P->spp;
+                for (int s0 = u0; s0 < u1; s0 += RTW_SUM_BLOCK) {
+                    v3 bsum = V(0.f, 0.f, 0.f);
+                    const int s1 = s0 + RTW_SUM_BLOCK < u1 ? s0 + RTW_SUM_BLOCK : u1;
+                    for (int s = s0; s < s1; s++) {
+                        v3 L = trace_path(sc, P, x, y, P->sample_offset + s, cn);
+                        bsum = vadd(bsum, L);
+                    }
+                    usum = vadd(usum, bsum);
                 }
-                sum = vadd(sum, bsum);
+                sum = vadd(sum, usum);
             }
             float n = (float)P->spp;
             float* o = out + 4 * ((size_t)l * (size_t)W + (size_t)x);

@@ -77,6 +77,7 @@ struct rtw_ctx {
     } lane[4];
     float4* accum = nullptr;   // per pixel: sum of the finished sample blocks
     float4* part = nullptr;    // per pixel: running sum of the current block (wavefront pipeline)
+    float4* upart = nullptr;   // per pixel: running sum of the current summation unit's finished blocks (wavefront pipeline)
     size_t accum_pix = 0;
     float4* blocksum = nullptr;  // k_path: [block][pixel] unit sums of one pass
     size_t blocksum_elems = 0;
@@ -206,6 +207,9 @@ int ensure_pool(rtw_ctx* c, int n_lanes, size_t paths, size_t npix, size_t cnt_w
         if (c->part) (void)hipFree(c->part);
         c->part = nullptr;
         HIP_TRY(c, hipMalloc(&c->part, npix * sizeof(float4)));
+        if (c->upart) (void)hipFree(c->upart);
+        c->upart = nullptr;
+        HIP_TRY(c, hipMalloc(&c->upart, npix * sizeof(float4)));
         c->accum_pix = npix;
     }
     if (!c->d_stats) HIP_TRY(c, hipMalloc(&c->d_stats, (kStatRows + 1) * 8 * sizeof(unsigned long long)));
@@ -487,6 +491,7 @@ int impl_destroy(rtw_ctx* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->accum) (void)hipFree(c->accum);
     if (c->part) (void)hipFree(c->part);
+    if (c->upart) (void)hipFree(c->upart);
     if (c->blocksum) (void)hipFree(c->blocksum);
     if (c->d_queue) (void)hipFree(c->d_queue);
     if (c->d_order) (void)hipFree(c->d_order);
@@ -917,13 +922,6 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
         int rc = ensure_pool(c, 0, 0, npix, 0);
         if (rc) return rc;
         const size_t n_blocks = ((size_t)P->spp + kSumBlock - 1) / kSumBlock;
-        const size_t pass_blocks = std::min<size_t>(n_blocks, std::max<size_t>(1, tune.blocksum_bytes / (npix * sizeof(float4))));
-        if (pass_blocks * npix > c->blocksum_elems) {
-            if (c->blocksum) (void)hipFree(c->blocksum);
-            c->blocksum = nullptr; c->blocksum_elems = 0;
-            HIP_TRY(c, hipMalloc(&c->blocksum, pass_blocks * npix * sizeof(float4)));
-            c->blocksum_elems = pass_blocks * npix;
-        }
         int wg_per_cu = tune.path_grid_mult;
         const size_t path_lds = path_tree ? lds : 0;
         if (wg_per_cu <= 0) {
@@ -970,12 +968,33 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
         // ends with its longest units, so long renders want long units and short ones short units. Measured on the metric
         // frame (1 620 blocks per lane): 8-block units 0.556 s, 4-block 0.562 s, 2-block 0.581 s; on its 1/8 shard (202
         // blocks per lane): 0.0773, 0.0722, 0.0736 s; on the 1/2 shard 8 and 4 are level.
-        const size_t blocks_per_lane = npix * std::min(pass_blocks, n_blocks) / ((size_t)c->n_cu * (size_t)wg_per_cu * kBlock);
+        const size_t blocks_per_lane = npix * n_blocks / ((size_t)c->n_cu * (size_t)wg_per_cu * kBlock);
         const size_t U = tune.path_unit_blocks > 0 ? (size_t)tune.path_unit_blocks : (blocks_per_lane >= 600 ? 8 : 4);
         const size_t F = (size_t)tune.path_fine_blocks;
+        // Sums in memory (the arithmetic spec's three levels, rtw.h): a bulk launch whose lane units are whole summation units
+        // (U a multiple of 8 blocks) stores ONE float4 per unit and pixel, everything else one per block; k_resolve_blocks adds
+        // them up in the spec's order. A pass covers a multiple of 8 blocks, so no summation unit straddles two passes.
+        const bool unit_sums = !path_tree && (U % kSumUnitBlocks) == 0;
+        auto coarse_of = [&](size_t nb) { return nb > 4 * F ? ((nb - F) / U) * U : (size_t)0; };  // short passes are all fine units
+        auto slots_of = [&](size_t nb) { const size_t nc = coarse_of(nb); return unit_sums ? nc / kSumUnitBlocks + (nb - nc) : nb; };
+        const size_t cap_slots = std::max<size_t>(1, tune.blocksum_bytes / (npix * sizeof(float4)));
+        size_t pass_blocks = n_blocks;
+        if (slots_of(n_blocks) > cap_slots) {
+            pass_blocks = kSumUnitBlocks;
+            while (pass_blocks + kSumUnitBlocks < n_blocks && slots_of(pass_blocks + kSumUnitBlocks) <= cap_slots) pass_blocks += kSumUnitBlocks;
+        }
+        size_t need_slots = 0;
+        for (size_t b0 = 0; b0 < n_blocks; b0 += pass_blocks) need_slots = std::max(need_slots, slots_of(std::min(pass_blocks, n_blocks - b0)));
+        if (need_slots * npix > c->blocksum_elems) {
+            if (c->blocksum) (void)hipFree(c->blocksum);
+            c->blocksum = nullptr; c->blocksum_elems = 0;
+            HIP_TRY(c, hipMalloc(&c->blocksum, need_slots * npix * sizeof(float4)));
+            c->blocksum_elems = need_slots * npix;
+        }
         for (size_t b0 = 0; b0 < n_blocks; b0 += pass_blocks) {
             const size_t nb = std::min(pass_blocks, n_blocks - b0);
-            size_t nb_coarse = nb > 4 * F ? ((nb - F) / U) * U : 0;  // short passes are all fine units
+            const size_t nb_coarse = coarse_of(nb);
+            const size_t slots_coarse = unit_sums ? nb_coarse / kSumUnitBlocks : nb_coarse;
             HIP_TRY_C(hipMemsetAsync(c->d_queue, 0, 4, s));
             HIP_TRY_C(hipMemsetAsync(c->d_queue + 4, 0, 4, s));
             hipEvent_t ev_a = nullptr, ev_b = nullptr;  // (from the call's event pool, like the wavefront lanes' start event)
@@ -1005,7 +1024,8 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
                 a.queue = c->d_queue + (part == 0 ? 0 : 4);
                 a.order = c->d_order;
                 a.order_counts = c->d_queue + 1;
-                a.blocksum = c->blocksum + first * npix;
+                a.blocksum = c->blocksum + (part == 0 ? 0 : slots_coarse) * npix;
+                a.unit_sums = (part == 0 && unit_sums) ? 1u : 0u;
                 a.n_jobs = (uint32_t)n_jobs; a.n_ranges = (uint32_t)n_ranges; a.units_per_job = (uint32_t)jb;
                 a.block0 = (uint32_t)(b0 + first); a.n_blocks_pass = (uint32_t)count; a.unit_blocks = (uint32_t)ub;
                 const int grid = (int)std::min<size_t>((size_t)c->n_cu * (size_t)wg_per_cu, (n_jobs + 3) / 4);
@@ -1022,9 +1042,14 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
                 HIP_TRY_C(hipEventRecord(tp.b, s));
                 ev_k.push_back(tp);
             }
-            hipLaunchKernelGGL(k_resolve_blocks, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->blocksum, c->accum, (uint32_t)npix, (uint32_t)nb);
+            // coarse region: whole unit sums (unit_sums) or block sums from block b0 on; fine region: block sums from b0 + nb_coarse on
+            if (unit_sums)
+                hipLaunchKernelGGL(k_resolve_blocks, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->blocksum, c->accum, (uint32_t)npix, (uint32_t)slots_coarse,
+                                   (uint32_t)(nb - nb_coarse), (uint32_t)(b0 + nb_coarse));
+            else
+                hipLaunchKernelGGL(k_resolve_blocks, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->blocksum, c->accum, (uint32_t)npix, 0u, (uint32_t)nb, (uint32_t)b0);
         }
-        hipLaunchKernelGGL(k_finish, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->accum, (const float4*)nullptr, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);
+        hipLaunchKernelGGL(k_finish, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->accum, (const float4*)nullptr, (const float4*)nullptr, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);
     } else {
     // ---- wavefront pipeline (tree scenes; RTW_PATH=0)
     // samples per pass: keep about pool_target paths in flight, split over the lanes
@@ -1117,6 +1142,7 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
     HIP_TRY_C(hipEventRecord(ev_begin, s));
     HIP_TRY_C(hipMemsetAsync(c->accum, 0, npix * sizeof(float4), s));
     HIP_TRY_C(hipMemsetAsync(c->part, 0, npix * sizeof(float4), s));
+    HIP_TRY_C(hipMemsetAsync(c->upart, 0, npix * sizeof(float4), s));
     HIP_TRY_C(hipMemsetAsync(c->d_stats, 0, (kStatRows + 1) * 8 * sizeof(unsigned long long), s));
 
     if (P->max_depth > 0) {
@@ -1209,7 +1235,7 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
             // batches are resolved into the accumulators in order, on the main stream
             if (er == hipSuccess) er = hipStreamWaitEvent(s, L.ev_done, 0);
             if (er != hipSuccess) return er;
-            hipLaunchKernelGGL(k_resolve, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)L.lbuf, c->accum, c->part, (uint32_t)npix, (uint32_t)R.Sb, (uint32_t)R.s0);
+            hipLaunchKernelGGL(k_resolve, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)L.lbuf, c->accum, c->upart, c->part, (uint32_t)npix, (uint32_t)R.Sb, (uint32_t)R.s0);
             return hipEventRecord(L.ev_free, s);
         };
         for (size_t s0 = 0; s0 < (size_t)P->spp;) {
@@ -1250,7 +1276,7 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
             }
         }
     }
-    hipLaunchKernelGGL(k_finish, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->accum, (const float4*)c->part, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);
+    hipLaunchKernelGGL(k_finish, dim3(pix_grid), dim3(kBlock), 0, s, (const float4*)c->accum, (const float4*)c->upart, (const float4*)c->part, (float4*)d_rgba, (uint32_t)npix, (float)P->spp);
     }
     HIP_TRY_C(hipGetLastError());
     HIP_TRY_C(hipEventRecord(ev_end, s));

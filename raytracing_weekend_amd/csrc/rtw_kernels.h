@@ -67,7 +67,9 @@ struct KArgs {
     uint32_t* queue;            // [0]: next job of the launch (one returning atomic per job and wave)
     float4* blocksum;           // [block - block0][shard-local pixel]: sum of the block's samples in sample order
     uint32_t n_jobs, n_ranges, units_per_job, block0, n_blocks_pass, spp;
-    uint32_t unit_blocks;       // consecutive sample blocks a lane takes as one unit (one 16-byte sum is stored per block)
+    uint32_t unit_blocks;       // consecutive sample blocks a lane takes as one unit
+    uint32_t unit_sums;         // 1: the lane units are whole aligned summation units (rtw.h RTW_SUM_UNIT_BLOCKS): one 16-byte sum is
+                                // stored per summation unit, slot [block / 8][pixel]; 0: one per block, slot [block][pixel]
     const uint32_t* order;      // job order of the 64-pixel groups: three lists, longest units first (k_classify)
     const uint32_t* order_counts;  // lengths of the lists of classes 2, 1, 0
 };
@@ -1314,6 +1316,7 @@ __global__ void __launch_bounds__(kBlock) k_classify(const KArgs A, uint32_t* __
 // and the per-pixel sums are taken block by block in order (k_resolve_blocks) - the summation order of the arithmetic spec.
 // The host runs a pass as two overlapping launches (rtw_hip.hip): the bulk in 4-block units, the last blocks one by one.
 constexpr uint32_t kSumBlock = RTW_SUM_BLOCK;
+constexpr uint32_t kSumUnitBlocks = RTW_SUM_UNIT_BLOCKS;
 constexpr int kPathMaxPrims = 64;  // k_path walks the brute lists only: scenes of at most this many primitives
 // RTW_MARK: a phase fence (see RTW_MARK2 above); the diagnostic build -DRTW_PHASE_TIMERS (never shipped) also accumulates
 // s_memtime deltas per phase and wave there (printed by the host)
@@ -1338,6 +1341,9 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
         const u32x4* src = (const u32x4*)A.sc.hitrec;
         for (uint32_t i = tid; i < (uint32_t)A.sc.n_prims * 6u; i += kBlock) s_hitrec[i] = src[i];
     }
+    // running sum of the lane's current summation unit (the sums of its finished blocks, in order): touched once per 16 samples,
+    // so it lives in LDS and costs the loop no register
+    __shared__ float s_usum[3][kBlock];
     __shared__ PathConsts s_pc;
     if (tid == 0) {
         for (int q = 0; q < 3; q++) {
@@ -1473,10 +1479,22 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
                 s_cur++;
                 if ((s_cur % kSumBlock) == 0u || s_cur >= A.spp) {  // a block is complete: its sum goes out, the unit moves on
                     const uint32_t yl_ = A.row_stride > 1 ? fastdiv(py - A.row0, A.divs_m, A.divs_s1, A.divs_s2) : py - A.row0;
-                    A.blocksum[(size_t)blk * A.npix + (yl_ * A.width + px)] = make_float4(usum.x, usum.y, usum.z, 0.f);
-                    usum = V(0.f, 0.f, 0.f);
+                    const uint32_t pix = yl_ * A.width + px;
+                    const uint32_t b_done = blk;
                     blk++;
                     need = blk >= blk_end || s_cur >= A.spp;
+                    if (A.unit_sums) {
+                        // the spec's second level: block sums add up in order inside aligned units of kSumUnitBlocks blocks
+                        // (the launch's first block is unit-aligned); the unit's sum is what is stored
+                        v3 prev = V(0.f, 0.f, 0.f);
+                        if ((b_done % kSumUnitBlocks) != 0u) prev = V(s_usum[0][tid], s_usum[1][tid], s_usum[2][tid]);
+                        const v3 u = vadd(prev, usum);
+                        if (need || (blk % kSumUnitBlocks) == 0u) A.blocksum[(size_t)(b_done / kSumUnitBlocks) * A.npix + pix] = make_float4(u.x, u.y, u.z, 0.f);
+                        else { s_usum[0][tid] = u.x; s_usum[1][tid] = u.y; s_usum[2][tid] = u.z; }
+                    } else {
+                        A.blocksum[(size_t)b_done * A.npix + pix] = make_float4(usum.x, usum.y, usum.z, 0.f);
+                    }
+                    usum = V(0.f, 0.f, 0.f);
                 }
             }
         }
@@ -1762,14 +1780,25 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
 
 #endif  // RTW_EXPERIMENTS
 
-// per-pixel sums, block by block in ascending order (the arithmetic spec's summation order: samples are summed in
-// order inside aligned blocks of kSumBlock, the block sums in order)
-__global__ void __launch_bounds__(kBlock) k_resolve_blocks(const float4* __restrict__ blocksum, float4* __restrict__ accum, uint32_t npix, uint32_t nblocks) {
+// per-pixel sums of one k_path pass in the arithmetic spec's order (rtw.h: samples in order inside blocks, block sums in order
+// inside aligned units of kSumUnitBlocks blocks, unit sums in order). slots: n_unit_slots whole unit sums [unit][pixel], then
+// n_block_slots block sums [block][pixel] whose first block (index first_block of the render call) is unit-aligned.
+__global__ void __launch_bounds__(kBlock) k_resolve_blocks(const float4* __restrict__ slots, float4* __restrict__ accum, uint32_t npix, uint32_t n_unit_slots,
+                                                           uint32_t n_block_slots, uint32_t first_block) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
         float4 a = accum[i];
-        for (uint32_t b = 0; b < nblocks; b++) {
-            const float4 l = blocksum[(size_t)b * npix + i];
+        for (uint32_t u = 0; u < n_unit_slots; u++) {
+            const float4 l = slots[(size_t)u * npix + i];
             a.x += l.x; a.y += l.y; a.z += l.z;
+        }
+        float ux = 0.f, uy = 0.f, uz = 0.f;
+        for (uint32_t b = 0; b < n_block_slots; b++) {
+            const float4 l = slots[(size_t)(n_unit_slots + b) * npix + i];
+            ux += l.x; uy += l.y; uz += l.z;
+            if (((first_block + b + 1u) % kSumUnitBlocks) == 0u || b + 1u == n_block_slots) {
+                a.x += ux; a.y += uy; a.z += uz;
+                ux = 0.f; uy = 0.f; uz = 0.f;
+            }
         }
         accum[i] = a;
     }
@@ -1800,32 +1829,44 @@ __global__ void __launch_bounds__(kBlock) k_atrous(const float4* __restrict__ in
     }
 }
 
-// Sums the S sample slots of every pixel in the arithmetic spec's order (rtw.h RTW_SUM_BLOCK): slot s is sample
-// first_sample + s of the render call; samples add up in order inside aligned blocks of kSumBlock (running block sum in
-// `part`), a finished block's sum is added to `accum`. Fixed order => reproducible bits, whatever the batch size.
-__global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ lbuf, float4* __restrict__ accum, float4* __restrict__ part, uint32_t npix,
-                                                    uint32_t nslots, uint32_t first_sample) {
+// Sums the S sample slots of every pixel in the arithmetic spec's order (rtw.h RTW_SUM_BLOCK, RTW_SUM_UNIT_BLOCKS): slot s is
+// sample first_sample + s of the render call; samples add up in order inside aligned blocks of kSumBlock (running block sum in
+// `part`), a finished block's sum is added to the running unit sum (`upart`), a finished unit's (kSumUnitBlocks blocks) to
+// `accum`. Fixed order => reproducible bits, whatever the batch size.
+__global__ void __launch_bounds__(kBlock) k_resolve(const float4* __restrict__ lbuf, float4* __restrict__ accum, float4* __restrict__ upart, float4* __restrict__ part,
+                                                    uint32_t npix, uint32_t nslots, uint32_t first_sample) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
-        float4 a = accum[i], b = part[i];
+        float4 a = accum[i], u = upart[i], b = part[i];
         for (uint32_t s = 0; s < nslots; s++) {
             const uint32_t rel = first_sample + s;
             if (rel != 0u && (rel % kSumBlock) == 0u) {
-                a.x += b.x; a.y += b.y; a.z += b.z;
+                u.x += b.x; u.y += b.y; u.z += b.z;
                 b = make_float4(0.f, 0.f, 0.f, 0.f);
+                if ((rel % (kSumBlock * kSumUnitBlocks)) == 0u) {
+                    a.x += u.x; a.y += u.y; a.z += u.z;
+                    u = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
             float4 l = lbuf[(size_t)s * npix + i];
             b.x += l.x; b.y += l.y; b.z += l.z;
         }
         accum[i] = a;
+        upart[i] = u;
         part[i] = b;
     }
 }
 
-// mean radiance: the last (possibly partial) block's sum joins the total, then the division by spp
-__global__ void __launch_bounds__(kBlock) k_finish(const float4* __restrict__ accum, const float4* __restrict__ part, float4* __restrict__ out, uint32_t npix, float spp) {
+// mean radiance: the last (possibly partial) block's sum joins its unit's, the last unit's sum the total, then the division by spp
+__global__ void __launch_bounds__(kBlock) k_finish(const float4* __restrict__ accum, const float4* __restrict__ upart, const float4* __restrict__ part,
+                                                   float4* __restrict__ out, uint32_t npix, float spp) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += gridDim.x * blockDim.x) {
         float4 a = accum[i];
-        if (part != nullptr) { const float4 b = part[i]; a.x += b.x; a.y += b.y; a.z += b.z; }
+        if (part != nullptr) {
+            float4 u = upart[i];
+            const float4 b = part[i];
+            u.x += b.x; u.y += b.y; u.z += b.z;
+            a.x += u.x; a.y += u.y; a.z += u.z;
+        }
         out[i] = make_float4(a.x / spp, a.y / spp, a.z / spp, 1.0f);
     }
 }
