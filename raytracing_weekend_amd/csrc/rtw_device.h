@@ -334,6 +334,7 @@ struct DScene {
     const rtw_light* __restrict__ lights;
     const u32x4* __restrict__ nodes;         // 4 vectors per node
     const u32x4* __restrict__ leaves;        // 2 vectors per leaf record
+    const u32x4* __restrict__ wnodes;        // the same tree with fp32 child boxes, 8 vectors per node (rtw_bvh.h WNode: traverse_wave)
     const int32_t* __restrict__ order;       // candidate order: volumes (index order) then the rest (index order)
     const BruteGroup* __restrict__ groups;   // small scenes: primitives regrouped by instance transform and kind
     const BruteRec* __restrict__ recs;
@@ -430,7 +431,15 @@ RTW_DEV TravMem trav_mem(const DScene& sc, uint32_t* lds, uint32_t block, uint32
     // entries down), the stack proper starts at row 2
     if (tm.wide) { lds[tid] = kBvhDone; lds[block + tid] = kBvhDone; }
     else { ((uint16_t*)lds)[tid] = 0xffffu; ((uint16_t*)lds)[block + tid] = 0xffffu; }
+    // A lane's 16-bit column inside a row of its wave: lane l sits in dword l % 32, half l / 32. LDS stores and dword reads are
+    // served in two groups of 32 lanes (banks of 4 bytes): with lanes 2k and 2k + 1 sharing a dword, two lanes of a group met on
+    // one bank whenever their stack heights differed (measured: SQ_LDS_BANK_CONFLICT 1.4x the LDS-active cycles of k_trace_bvh);
+    // this way every lane of a group has a bank of its own whatever the heights.
+#ifndef RTW_STACK_LINEAR
+    tm.stack16 = (uint16_t*)lds + 2u * block + ((tid & ~63u) | ((tid & 31u) << 1) | ((tid >> 5) & 1u));
+#else
     tm.stack16 = (uint16_t*)lds + 2u * block + tid;
+#endif
     tm.stack32 = lds + 2u * block + tid;
     tm.stride = block;
     const uint32_t stack_words = tm.wide ? (uint32_t)sc.stack_depth * block : ((uint32_t)sc.stack_depth * block + 1u) / 2u;
@@ -1059,6 +1068,91 @@ RTW_DEV void traverse(const DScene& sc, v3 o, v3 d, float tmin, float tmax, floa
         if (cur == kBvhDone) break;
     }
 #undef RTW_ACCEPT
+}
+
+// ---- camera rays: the wave walks the tree as one ---------------------------------------------------------------------
+// k_first's rays leave through a few neighbouring pixels, so they visit nearly the same nodes. Here the WAVE stands at one
+// node at a time: the node record (fp32 child boxes: rtw_bvh.h WNode) arrives through the scalar cache as instruction
+// operands, every lane tests its own ray against the four boxes (6 fused multiply-adds, min / max and one compare per child
+// instead of 12 conversions + multiply-adds and the per-lane stack traffic of bvh_step16), ballots say which children anyone
+// needs, the nearest (by the entry distance of the first lane that wants it) is entered and the others go onto the wave's own
+// stack in LDS - one 32-bit entry per level, in the space of the wave's per-lane stack columns, which this walk does not use.
+// Leaves are tested by every lane with the record as scalar operands. A lane that missed a box runs through its subtree with
+// the others and finds nothing there (boxes contain their primitives), and the closest hit is the minimum over (t, primitive
+// index) of the candidates a lane hits whatever the order: per lane the result is traverse<>'s, bit for bit.
+// wave_stack: this wave's level 0; level_stride: dwords between levels. live = false: the lane takes part in nothing.
+RTW_DEV void traverse_wave(const DScene& sc, uint32_t* wave_stack, const uint32_t level_stride, const bool live, const v3 o, const v3 d, const float tmin,
+                           const float ray_time, const float gather_time, float& best_t, int& best_prim, bool best_is_vol) {
+    if (sc.n_tree <= 0) return;
+    const v3 inv = recip3(d);
+    const float ix = __builtin_amdgcn_fmed3f(inv.x, -1.0e18f, 1.0e18f), iy = __builtin_amdgcn_fmed3f(inv.y, -1.0e18f, 1.0e18f),
+                iz = __builtin_amdgcn_fmed3f(inv.z, -1.0e18f, 1.0e18f);
+    const float nx = -(o.x * ix), ny = -(o.y * iy), nz = -(o.z * iz);
+    TravMem tm0;  // leaf records come through the scalar cache here, not from the workgroup's LDS image
+    tm0.stack16 = nullptr; tm0.stack32 = nullptr; tm0.stride = 0; tm0.nodes = nullptr; tm0.n_nodes = 0; tm0.leaves = nullptr; tm0.n_leaves = 0; tm0.wide = false;
+    uint32_t cur = 0u;  // wave-uniform from here on: the reference the wave stands at
+    uint32_t sp = 0u;
+    for (;;) {
+        while ((cur & 3u) == 0u) {
+            const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.wnodes + 8u * (cur >> 2));
+            const u32x4 b0 = q[0], b1 = q[1], b2 = q[2], b3 = q[3], b4 = q[4], b5 = q[5], rf = q[6];
+            uint32_t key[4];
+#define RTW_W_CHILD(C_, LX_, LY_, LZ_, HX_, HY_, HZ_, REF_)                                                                                        \
+            {                                                                                                                                    \
+                key[C_] = 0xffffffffu;                                                                                                           \
+                if ((REF_) != kBvhDone) {                                                                                                        \
+                    const float ax = fma_(__uint_as_float(LX_), ix, nx), bx = fma_(__uint_as_float(HX_), ix, nx);                                 \
+                    const float ay = fma_(__uint_as_float(LY_), iy, ny), by = fma_(__uint_as_float(HY_), iy, ny);                                 \
+                    const float az = fma_(__uint_as_float(LZ_), iz, nz), bz = fma_(__uint_as_float(HZ_), iz, nz);                                 \
+                    const float tn = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), tmin)); \
+                    const float tf = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), best_t)); \
+                    const unsigned long long any = __ballot(live && tn <= tf);                                                                   \
+                    if (any != 0ull)                                                                                                             \
+                        key[C_] = ((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tn), (int)__builtin_ctzll(any)) & ~3u) | (uint32_t)C_; \
+                }                                                                                                                                \
+            }
+            RTW_W_CHILD(0, b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, rf.x)
+            RTW_W_CHILD(1, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, rf.y)
+            RTW_W_CHILD(2, b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, rf.z)
+            RTW_W_CHILD(3, b4.z, b4.w, b5.x, b5.y, b5.z, b5.w, rf.w)
+#undef RTW_W_CHILD
+            // tn >= tmin > 0: the entry distances order as unsigned integers; children nobody wants sort last
+            uint32_t k0 = key[0], k1 = key[1], k2 = key[2], k3 = key[3], t_;
+#define RTW_CSWAP(A_, B_) { t_ = min(A_, B_); B_ = max(A_, B_); A_ = t_; }
+            RTW_CSWAP(k0, k1) RTW_CSWAP(k2, k3) RTW_CSWAP(k0, k2) RTW_CSWAP(k1, k3) RTW_CSWAP(k1, k2)
+#undef RTW_CSWAP
+#define RTW_W_REF(K_) (((K_) & 3u) == 0u ? rf.x : ((K_) & 3u) == 1u ? rf.y : ((K_) & 3u) == 2u ? rf.z : rf.w)
+            // the farthest wanted child goes down first, the nearest is entered
+            if (k3 != 0xffffffffu) { wave_stack[sp * level_stride] = RTW_W_REF(k3); sp++; }
+            if (k2 != 0xffffffffu) { wave_stack[sp * level_stride] = RTW_W_REF(k2); sp++; }
+            if (k1 != 0xffffffffu) { wave_stack[sp * level_stride] = RTW_W_REF(k1); sp++; }
+            if (k0 != 0xffffffffu) {
+                cur = RTW_W_REF(k0);
+            } else if (sp > 0u) {
+                sp--;
+                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_stack[sp * level_stride]);
+            } else {
+                cur = kBvhDone;
+            }
+#undef RTW_W_REF
+        }
+        if (cur == kBvhDone) break;
+        uint32_t slot = cur >> 2;
+        const uint32_t cnt = cur & 3u;
+        for (uint32_t k = 0; k < cnt; k++) {
+            int pi;
+            float t;
+            uint32_t next;
+            const bool hit = leaf_test(sc, tm0, slot, o, d, inv, tmin, ray_time, gather_time, t, pi, next);
+            if (live && hit && (t < best_t || (t == best_t && best_prim >= 0 && !best_is_vol && pi < best_prim))) {
+                best_t = t; best_prim = pi; best_is_vol = false;
+            }
+            slot = (uint32_t)__builtin_amdgcn_readfirstlane((int)next);
+        }
+        if (sp == 0u) break;
+        sp--;
+        cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_stack[sp * level_stride]);
+    }
 }
 
 // Radiance ray (closest hit) and queued shadow probe (any hit) of one path in ONE walk over the small-scene

@@ -727,7 +727,24 @@ int impl_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     size_t o_lights = al(o_shade + shade.size() * sizeof(HitRec));
     size_t o_clights = al(o_lights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
     size_t o_nodes = al(o_clights + std::max<size_t>(1, lights.size()) * sizeof(rtw_light));
-    size_t o_tree = al(o_nodes + std::max<size_t>(1, bvh.q4.size()) * sizeof(rtwbvh::Q4Node));
+    // the wave-coherent walk's nodes: fp32 child boxes, padded for its plane arithmetic. It computes a plane's distance as
+    // fma(plane, 1/d, -(o * 1/d)): the rounding of o * 1/d displaces a plane by about ulp(|o|) in space, so the boxes grow by
+    // 2^-19 of the largest coordinate around (scene bounds, camera origin; the primitives' own bounds carry 1e-4 already)
+    if (use_bvh) {
+        float big = 1.0f;
+        for (uint32_t i = 0; i < h.n_prims; i++) {
+            const rtwbvh::Box wb = rtwbvh::world_bounds(prims[i], xforms[prims[i].xform]);
+            for (int a = 0; a < 3; a++) big = std::max(big, std::max(std::fabs(wb.mn[a]), std::fabs(wb.mx[a])));
+        }
+        for (int a = 0; a < 3; a++) big = std::max(big, std::fabs(h.camera.origin[a]) + std::fabs(h.camera.lens_radius));
+        const float pad = 1.0e-4f + big * (1.0f / 524288.0f);
+        for (rtwbvh::WNode& w : bvh.wq4)
+            for (int k = 0; k < 4; k++)
+                if (w.ref[k] != rtwbvh::kQ4Empty)
+                    for (int a = 0; a < 3; a++) { w.box[k][a] -= pad; w.box[k][3 + a] += pad; }
+    }
+    size_t o_wnodes = al(o_nodes + std::max<size_t>(1, bvh.q4.size()) * sizeof(rtwbvh::Q4Node));
+    size_t o_tree = al(o_wnodes + std::max<size_t>(1, bvh.wq4.size()) * sizeof(rtwbvh::WNode));
     size_t o_order = al(o_tree + std::max<size_t>(1, bvh.leaves.size()) * sizeof(rtwbvh::LeafRec));
     size_t o_groups = al(o_order + std::max<size_t>(1, order.size()) * sizeof(int32_t));
     size_t o_recs = al(o_groups + std::max<size_t>(1, groups.size()) * sizeof(BruteGroup));
@@ -742,6 +759,7 @@ int impl_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     if (!lights.empty()) memcpy(stage.data() + o_lights, lights.data(), lights.size() * sizeof(rtw_light));
     if (!clights.empty()) memcpy(stage.data() + o_clights, clights.data(), clights.size() * sizeof(rtw_light));
     if (!bvh.q4.empty()) memcpy(stage.data() + o_nodes, bvh.q4.data(), bvh.q4.size() * sizeof(rtwbvh::Q4Node));
+    if (!bvh.wq4.empty()) memcpy(stage.data() + o_wnodes, bvh.wq4.data(), bvh.wq4.size() * sizeof(rtwbvh::WNode));
     if (!bvh.leaves.empty()) memcpy(stage.data() + o_tree, bvh.leaves.data(), bvh.leaves.size() * sizeof(rtwbvh::LeafRec));
     if (!order.empty()) memcpy(stage.data() + o_order, order.data(), order.size() * sizeof(int32_t));
     if (!groups.empty()) memcpy(stage.data() + o_groups, groups.data(), groups.size() * sizeof(BruteGroup));
@@ -767,6 +785,7 @@ int impl_upload_scene(rtw_ctx* c, const void* blob, size_t bytes) {
     sc.estimator = RTW_EST_REFERENCE; sc.ray_tmin = 1e-6f; sc.probe_eps = 500 * 1.0e-7f;  // set per render
     sc.nodes = (const u32x4*)(d + o_nodes);
     sc.leaves = (const u32x4*)(d + o_tree);
+    sc.wnodes = (const u32x4*)(d + o_wnodes);
     sc.order = (const int32_t*)(d + o_order);
     sc.groups = (const BruteGroup*)(d + o_groups);
     sc.recs = (const BruteRec*)(d + o_recs);
@@ -1301,6 +1320,22 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
         fprintf(stderr, " (total %.3g wave-cycles, %.0f per 64 segments)\n", tot, tot / ((double)hs[0] / 64.0));
         if (path_tree) fprintf(stderr, "[rtw] k_path_tree wave steps per 64 segments: inner %.1f  leaf %.1f  shade %.2f\n", (double)ph[6] / ((double)hs[0] / 64.0),
                                (double)(ph[7] % 1000000ull) / ((double)hs[0] / 64.0), (double)(ph[7] / 1000000ull) / ((double)hs[0] / 64.0));
+    }
+#endif
+#ifdef RTW_SUBPHASE_TIMERS
+    if (use_path) {
+        static std::vector<unsigned long long> tab((size_t)kSubWaves * kSubRows);
+        HIP_TRY_C(hipMemcpyFromSymbol(tab.data(), HIP_SYMBOL(g_sub_cyc), tab.size() * sizeof(unsigned long long)));
+        double sum[kSubRows] = {0};
+        for (size_t w = 0; w < (size_t)kSubWaves; w++) for (int q = 0; q < 14; q++) sum[q] += (double)tab[w * kSubRows + q];
+        double tot = 0;
+        for (int q = 0; q < 14; q++) tot += sum[q];
+        const char* nm[9] = {"outside", "hitrec+philox", "lambert", "light", "metal", "diel", "iso", "nee", "entry"};
+        fprintf(stderr, "[rtw] k_path wave-cycles by sub-phase of the closest-hit program:");
+        for (int q = 0; q < 9; q++) fprintf(stderr, " %s %.1f%%", nm[q], 100.0 * sum[q] / tot);
+        fprintf(stderr, " (total %.3g)\n", tot);
+        std::fill(tab.begin(), tab.end(), 0ull);
+        HIP_TRY_C(hipMemcpyToSymbol(HIP_SYMBOL(g_sub_cyc), tab.data(), tab.size() * sizeof(unsigned long long)));
     }
 #endif
 #ifdef RTW_TRACE_COUNT

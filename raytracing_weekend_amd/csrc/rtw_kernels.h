@@ -39,7 +39,32 @@ using namespace rtwdev;
 // address arithmetic of later phases over earlier ones until the 96-register budget of 5 waves per SIMD overflows (88 bytes
 // of scratch per lane in the hot loop); with a fence at every phase boundary the same code allocates without a spill and
 // the metric workload runs 3.5 % faster. scripts/isa_phases.sh counts instructions between the comments.
+#ifdef RTW_SUBPHASE_TIMERS
+// Diagnostic build only (scripts/build_variant.sh sub -DRTW_SUBPHASE_TIMERS): wave-cycles between the sub-phase fences of the
+// closest-hit program, accumulated per wave in a private row of a device-global table (row 14: id of the open interval, row
+// 15: its start); the bookkeeping itself lies outside the measured intervals. Printed by the host after a k_path render.
+constexpr int kSubRows = 16, kSubWaves = 8192;
+__device__ unsigned long long g_sub_cyc[kSubWaves][kSubRows];
+RTW_DEV constexpr int rtw_sub_id(const char* n) {  // "sa_hitrec" 1, "sa_lambert" 2, "sa_light" 3, "sa_metal" 4, "sa_diel" 5, "sa_iso" 6, "sa_nee" 7, other 0
+    return n[0] != 's' || n[1] != 'a' ? 0 : n[3] == 'h' ? 1 : n[3] == 'l' && n[4] == 'a' ? 2 : n[3] == 'l' ? 3 : n[3] == 'm' ? 4 : n[3] == 'd' ? 5 : n[3] == 'i' ? 6 : n[3] == 'n' ? 7 : 0;
+}
+RTW_DEV void rtw_sub_stamp(int id) {
+    const unsigned long long t_in = __builtin_amdgcn_s_memtime();
+    if ((threadIdx.x & 63u) == 0u) {
+        unsigned long long* row = g_sub_cyc[(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) % kSubWaves];
+        const unsigned long long open_id = row[14], t0 = row[15];
+        if (t0 != 0ull) row[open_id] += t_in - t0;
+        row[14] = (unsigned long long)id;
+        __builtin_amdgcn_s_waitcnt(0);
+        row[15] = __builtin_amdgcn_s_memtime();
+    }
+}
 #define RTW_MARK2(name) asm volatile("; MARK " name)
+#define RTW_SUB(id) rtw_sub_stamp(id)
+#else
+#define RTW_MARK2(name) asm volatile("; MARK " name)
+#define RTW_SUB(id)
+#endif
 constexpr int kBlock = 256;                       // 4 wave64 per workgroup
 constexpr uint32_t kMaxRegions = 2048;            // region counters scanned in LDS by every workgroup (>= the compacting grid)
 constexpr uint32_t kZombie = 0x80000000u;
@@ -269,6 +294,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
         return EV_MISS;
     }
     RTW_MARK2("sa_hitrec");
+    RTW_SUB(1);
     g.align_block();
     const HitRec hr = load_hitrec(sc, prim, hr_lds);
     // the segment's first Philox block, generated while the whole wave is on one code path and - not depending on the hit
@@ -284,6 +310,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     bool specular = false;
     RTW_MARK2("sa_lambert");
     if (mtype == RTW_MAT_LAMBERTIAN) {
+        RTW_SUB(2);
         // lambertianMaterial.cu:41-71, onb.cuh:20-32, sampling.cuh:49-60 (Q1)
         v3 u, v, w;
         if (hr.kind == HK_CONST_NORMAL) {  // basis baked per primitive at upload, same operations
@@ -323,6 +350,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     RTW_MARK2("sa_light");
     } else if (mtype == RTW_MAT_DIFFUSE_LIGHT) {
         // diffuseLight.cu:48-69
+        RTW_SUB(3);
         if (dot3(hn, dir) < 0.0f) radiance = tex;
         // corrected: the light sample of the previous vertex already accounted for this emitter
         if (est == RTW_EST_CORRECTED && had_nee != 0u && hr.listed != 0) radiance = V(0.f, 0.f, 0.f);
@@ -330,6 +358,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     RTW_MARK2("sa_metal");
     } else if (mtype == RTW_MAT_METAL) {
         // metalMaterial.cu:32-64 (Q5)
+        RTW_SUB(4);
         specular = true;
         v3 refl = reflect3(est ? normalize3(dir) : dir, hn);  // corrected: unit incoming direction (Q5)
         v3 ball = random_in_unit_sphere(g);
@@ -340,6 +369,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     RTW_MARK2("sa_diel");
     } else if (mtype == RTW_MAT_DIELECTRIC) {
         // dielectricMaterial.cu:37-114
+        RTW_SUB(5);
         specular = true;
         v3 unit = normalize3(dir);
         v3 ln;
@@ -374,6 +404,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     RTW_MARK2("sa_iso");
     } else if (mtype == RTW_MAT_ISOTROPIC) {
         // isotropicMaterial.cu:30-51 (Q14)
+        RTW_SUB(6);
         specular = true;
         sd = random_in_unit_sphere(g);
         so = hp;
@@ -387,6 +418,7 @@ RTW_DEV int shade_a(const DScene& sc, Rng<KIND>& g, const v3 origin, const v3 di
     }
 
     RTW_MARK2("sa_nee");
+    RTW_SUB(7);
     // next-event estimation, closehit.cu:70-94: sample the light; the visibility probe comes later
     const int nl = sc.n_lights;
     if (est == RTW_EST_CORRECTED && ev == EV_HIT && !specular && nl > 0) {
@@ -726,8 +758,11 @@ RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const ui
 }
 
 // ------------------------------------------------------------------ k_first
+#ifndef RTW_FIRST_WAVES
+#define RTW_FIRST_WAVES RTW_MIN_WAVES
+#endif
 template <int KIND, int TEX>
-__global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) {
+__global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_FIRST_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_CURSOR_SHARED
     RTW_NOISE_SHARED
@@ -771,6 +806,17 @@ __global__ void __launch_bounds__(kBlock, RTW_MIN_WAVES) k_first(const KArgs A) 
             // and a wave-uniform test against the scene bounds spares them the walk over the candidate lists
             th = 1.e27f; prim = -1;
             if (__ballot(may_hit_scene(A.sc, p.o, p.d)) != 0ull) {
+#ifndef RTW_FIRST_LANE_WALK
+                if (A.sc.use_bvh) {
+                    // the camera rays of a wave walk the tree together (rtw_device.h traverse_wave); volumes first, per lane, as in
+                    // traverse<>. The wave's stack: one 32-bit entry per level in the rows of its per-lane stack columns
+                    bool vol = false;
+                    if (TEX && A.sc.n_vol > 0) vol = volume_pass<Rng<KIND>, false>(A.sc, p.o, p.d, A.sc.ray_tmin, p.ray_time, gt, g, th, prim);
+                    const uint32_t wv = tid >> 6;
+                    uint32_t* wstack = tm.wide ? s_stack + 2u * kBlock + 64u * wv : s_stack + kBlock + 32u * wv;
+                    traverse_wave(A.sc, wstack, tm.wide ? (uint32_t)kBlock : (uint32_t)kBlock / 2u, true, p.o, p.d, A.sc.ray_tmin, p.ray_time, gt, th, prim, vol);
+                } else
+#endif
                 if (TEX && A.sc.n_vol > 0) traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, g, tm, th, prim);
                 else traverse<NoRng, false, true>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
             }
@@ -1044,14 +1090,16 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
 #define RTW_SHADE_WAVES RTW_MIN_WAVES
 #endif
 // RTW_SHADE_SORT=1 (experiment, off): deal a chunk's paths to the threads by hit material. Measured: k_shade 4-7 % SLOWER on
-// scenes 1, 2, 4 with one lane or two - the kernel moves 170-185 B per segment at the HBM copy rate, its serialised material
-// branches hide behind that, and the sort adds a dependent load (hit record -> material) in front of the path loads.
+// scenes 1, 2, 4 with one lane or two. Round 3 repeated it with the material class carried in the hit record (no lookup at all) and
+// the next chunk's hit records fetched a chunk ahead: still 4 % slower on scene 1, 1-2 % on scenes 2 and 4 (bit-exact). The kernel
+// waits on its path loads (61 % of its wave-cycles, rocprofv3 round 3) and issues VALU for 22 % of them: the serialised material
+// branches hide behind the loads, and the sort's two barriers and permuted loads do not.
 #if !defined(RTW_SHADE_SORT) || !defined(RTW_EXPERIMENTS)
 #undef RTW_SHADE_SORT
 #define RTW_SHADE_SORT 0
 #endif
 template <int KIND, int TEX>
-__global__ void __launch_bounds__(kBlock, RTW_SHADE_WAVES) k_shade(const KArgs A) {
+__global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_SHADE_WAVES) k_shade(const KArgs A) {
     RTW_WORKLIST_SHARED
     RTW_CURSOR_SHARED
     RTW_NOISE_SHARED
@@ -1450,11 +1498,17 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
             }
         }
         RTW_MARK("shade_a");
+#ifdef RTW_SUBPHASE_TIMERS
+        rtw_sub_stamp(8);   // 8: shade_a entry (miss test, branch to the hit code)
+#endif
         if (busy) {
             v3 so, sd, att, radiance;
             Nee nee;
             const int ev = shade_a<KIND, TEX>(A.sc, g, o, d, gt, th, prim, so, sd, att, radiance, nee, noise_lds, nee_prev, s_hitrec, &s_pc);
             n_seg++;
+#ifdef RTW_SUBPHASE_TIMERS
+            rtw_sub_stamp(0);  // 0: everything outside the closest-hit program
+#endif
             RTW_MARK("walk_s");
             if (nee.has) {  // traceOcclusion, closehit.cu:16-42
                 float st;
