@@ -46,6 +46,23 @@
 using namespace rtwdev;
 using namespace rtwk;
 
+#ifdef RTW_SPLIT_BUILD
+// __graft_entry__.build() compiles the shading kernels in translation units of their own, in parallel (rtw_inst_path.hip,
+// rtw_inst_shade.hip): here they are only declared
+namespace rtwk {
+#define RTW_EXT(K_) \
+    extern template __global__ void K_<RTW_RNG_PHILOX, 0>(const KArgs); extern template __global__ void K_<RTW_RNG_PHILOX, 1>(const KArgs); extern template __global__ void K_<RTW_RNG_PHILOX, 2>(const KArgs); \
+    extern template __global__ void K_<RTW_RNG_TEA_LCG, 0>(const KArgs); extern template __global__ void K_<RTW_RNG_TEA_LCG, 1>(const KArgs); extern template __global__ void K_<RTW_RNG_TEA_LCG, 2>(const KArgs);
+RTW_EXT(k_path)
+RTW_EXT(k_first)
+RTW_EXT(k_shade)
+RTW_EXT(k_bounce)
+#undef RTW_EXT
+extern template __global__ void k_classify<true>(const KArgs, uint32_t*, uint32_t*, uint32_t);
+extern template __global__ void k_classify<false>(const KArgs, uint32_t*, uint32_t*, uint32_t);
+}  // namespace rtwk
+#endif
+
 constexpr int kBruteMaxPrims = 24;  // at or below: scalar-cache brute lists; above: BVH with the LDS stack
 
 // =============================================================================================

@@ -1834,6 +1834,7 @@ __global__ void __launch_bounds__(kBlock, RTW_TREE_WAVES) k_path_tree(const KArg
 
 #endif  // RTW_EXPERIMENTS
 
+#ifndef RTW_TEMPLATES_ONLY  // (the translation units that only instantiate the shading kernels leave the plain kernels to rtw_hip.hip)
 // per-pixel sums of one k_path pass in the arithmetic spec's order (rtw.h: samples in order inside blocks, block sums in order
 // inside aligned units of kSumUnitBlocks blocks, unit sums in order). slots: n_unit_slots whole unit sums [unit][pixel], then
 // n_block_slots block sums [block][pixel] whose first block (index first_block of the render call) is unit-aligned.
@@ -1941,5 +1942,7 @@ __global__ void __launch_bounds__(kBlock) k_debug_intersect(const DScene sc, con
     out_t[i] = t;
     out_prim[i] = prim;
 }
+
+#endif  // RTW_TEMPLATES_ONLY
 
 }  // namespace rtwk
