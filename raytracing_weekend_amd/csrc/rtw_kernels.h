@@ -117,6 +117,9 @@ struct PathConsts {
     float cam_o[4], cam_ll[4], cam_h[4], cam_v[4];
     float rect[5]; int32_t gen; float pad[2];
     float lnrm[3], larea, lemi[3], pad2;
+    // what the end of a sample block needs (k_path: a branch that one or two lanes of a wave take in two iterations out of three):
+    // read from here, these launch constants do not sit in SGPRs - which the loop has none to spare of - between those visits
+    uint32_t npix, width, row0, row_stride, divs_m, divs_s1, divs_s2, spp, bs_lo, bs_hi, unit_shift, pad3;
 };
 
 // probes = the scene lists lights: only then can a vertex queue a shadow probe (shade_a), so plane p2 - the probe's
@@ -1406,6 +1409,10 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
             for (int q = 0; q < 3; q++) { s_pc.lnrm[q] = A.sc.lights[0].normal[q]; s_pc.lemi[q] = A.sc.lights[0].emission[q]; }
             s_pc.larea = A.sc.lights[0].area;
         }
+        s_pc.npix = A.npix; s_pc.width = A.width; s_pc.row0 = A.row0; s_pc.row_stride = A.row_stride;
+        s_pc.divs_m = A.divs_m; s_pc.divs_s1 = A.divs_s1; s_pc.divs_s2 = A.divs_s2; s_pc.spp = A.spp;
+        s_pc.bs_lo = (uint32_t)(uint64_t)A.blocksum; s_pc.bs_hi = (uint32_t)((uint64_t)A.blocksum >> 32);
+        s_pc.unit_shift = A.unit_sums ? 3u : 0u; s_pc.pad3 = 0u;
     }
     // the LDS camera serves the perspective camera without a lens (the reference's only camera); other kinds read the arguments
     // (the host sends other camera kinds and thin lenses through the cold instantiation, which reads the arguments)
@@ -1532,22 +1539,24 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
                 usum = vadd(usum, V((L.x == L.x) ? L.x : 0.f, (L.y == L.y) ? L.y : 0.f, (L.z == L.z) ? L.z : 0.f));
                 s_cur++;
                 if ((s_cur % kSumBlock) == 0u || s_cur >= A.spp) {  // a block is complete: its sum goes out, the unit moves on
-                    const uint32_t yl_ = A.row_stride > 1 ? fastdiv(py - A.row0, A.divs_m, A.divs_s1, A.divs_s2) : py - A.row0;
-                    const uint32_t pix = yl_ * A.width + px;
+                    const PathConsts* kc = &s_pc;  // (launch constants from the LDS page: see PathConsts)
+                    const uint32_t c_row0 = kc->row0, c_stride = kc->row_stride, c_width = kc->width, c_npix = kc->npix;
+                    const uint32_t yl_ = c_stride > 1 ? fastdiv(py - c_row0, kc->divs_m, kc->divs_s1, kc->divs_s2) : py - c_row0;
+                    const uint32_t pix = yl_ * c_width + px;
                     const uint32_t b_done = blk;
                     blk++;
                     need = blk >= blk_end || s_cur >= A.spp;
-                    if (A.unit_sums) {
-                        // the spec's second level: block sums add up in order inside aligned units of kSumUnitBlocks blocks
-                        // (the launch's first block is unit-aligned); the unit's sum is what is stored
-                        v3 prev = V(0.f, 0.f, 0.f);
-                        if ((b_done % kSumUnitBlocks) != 0u) prev = V(s_usum[0][tid], s_usum[1][tid], s_usum[2][tid]);
-                        const v3 u = vadd(prev, usum);
-                        if (need || (blk % kSumUnitBlocks) == 0u) A.blocksum[(size_t)(b_done / kSumUnitBlocks) * A.npix + pix] = make_float4(u.x, u.y, u.z, 0.f);
-                        else { s_usum[0][tid] = u.x; s_usum[1][tid] = u.y; s_usum[2][tid] = u.z; }
-                    } else {
-                        A.blocksum[(size_t)b_done * A.npix + pix] = make_float4(usum.x, usum.y, usum.z, 0.f);
-                    }
+                    float4* const bsum_base = (float4*)(((uint64_t)kc->bs_hi << 32) | kc->bs_lo);
+                    // the spec's second level: block sums add up in order inside aligned units of kSumUnitBlocks blocks (the launch's
+                    // first block is unit-aligned). A launch whose lane units are whole summation units (A.unit_sums: shift 3) keeps
+                    // the unit's running sum in LDS and stores the unit's sum, slot [block / 8][pixel]; any other stores every
+                    // block's sum, slot [block][pixel] (0 + x = x: the same bits as storing x).
+                    const uint32_t ush = kc->unit_shift;
+                    v3 prev = V(0.f, 0.f, 0.f);
+                    if (ush != 0u && (b_done % kSumUnitBlocks) != 0u) prev = V(s_usum[0][tid], s_usum[1][tid], s_usum[2][tid]);
+                    const v3 u = vadd(prev, usum);
+                    if (ush == 0u || need || (blk % kSumUnitBlocks) == 0u) bsum_base[(size_t)(b_done >> ush) * c_npix + pix] = make_float4(u.x, u.y, u.z, 0.f);
+                    else { s_usum[0][tid] = u.x; s_usum[1][tid] = u.y; s_usum[2][tid] = u.z; }
                     usum = V(0.f, 0.f, 0.f);
                 }
             }

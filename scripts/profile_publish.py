@@ -1,29 +1,48 @@
-"""usage: python scripts/profile_publish.py <gpurun_out/profile_TAG> <rNN> : copies the summaries of a scripts/profile_round2.sh run
-into profiles/ (tracked) under the round's prefix and regenerates profiles/pmc_traffic.json, the per-segment figures bench.py
-scales into roofline.traffic / roofline.valu."""
+"""usage: python scripts/profile_publish.py <gpurun_out/profile_TAG> <rNN> : copies the summaries of a scripts/profile_round3.sh run into
+profiles/ (tracked) under the round's prefix and regenerates profiles/pmc_traffic.json - the per-UNIT traffic and instruction
+figures, per configuration and kernel, that bench.py scales into roofline.traffic / roofline.valu / roofline.per_kernel."""
 import json, os, shutil, sys
 src, rnd = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 dst = os.path.join(root, "profiles")
-for name, out in (("kernel_stats.csv", "kernel_stats.csv"), ("bench_under_rocprof.json", "bench_under_rocprof.json"), ("pmc_k_path.json", "pmc_k_path.json"),
-                  ("bench.json", "bench.json"), ("bench_configs.jsonl", "bench_configs.jsonl"),
-                  ("pmc_k_trace_bvh_scene1.json", "pmc_k_trace_bvh_scene1.json"), ("kernel_stats_scene1.csv", "kernel_stats_scene1.csv"),
-                  ("kernel_stats_scene4.csv", "kernel_stats_scene4.csv")):
+copied = []
+for name in sorted(os.listdir(src)):
     p = os.path.join(src, name)
-    if os.path.exists(p) and os.path.getsize(p):
-        shutil.copy(p, os.path.join(dst, f"{rnd}_{out}"))
-pm = json.load(open(os.path.join(src, "pmc_k_path.json")))
-d = pm["derived"]
-traffic = {
-    "k_path": {"hbm_bytes_per_segment": d["hbm_bytes_per_segment"], "valu_insts_per_segment": d["valu_insts_per_segment"],
-               "salu_insts_per_segment": d["salu_insts_per_segment"], "lane_utilisation": d["lane_utilisation"], "segments_profiled": d["segments"],
-               "source": f"profiles/{rnd}_pmc_k_path.json: scripts/pmc_kernel.sh, rocprofv3 --pmc passes of `scripts/bench_scene.py 0 1920 1080 256 50` "
-                         "(the metric scene, one k_path launch); HBM bytes = FETCH_SIZE x 2 (gfx950 wide-read correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE, KiB -> B"},
-    # wavefront kernels (tree scenes, RTW_PATH=0): round-1 measurement restated per segment (profiles/r01_pmc_summary.json: bytes of all
-    # launches of a 128-spp render / the segments those launches shaded)
-    "k_shade": {"hbm_bytes_per_segment": 57.93e9 / 306.8e6, "source": "profiles/r01_pmc_summary.json (15 launches, 306.8 M segments)"},
-    "k_first": {"hbm_bytes_per_segment": 15.11e9 / 265.4e6, "source": "profiles/r01_pmc_summary.json (3 launches, 265.4 M camera paths)"},
-}
+    if not os.path.isfile(p) or not os.path.getsize(p):
+        continue
+    if name.endswith((".csv", ".json", ".jsonl")):
+        shutil.copy(p, os.path.join(dst, f"{rnd}_{name}"))
+        copied.append(name)
+print("copied", copied)
+
+
+def entries(pmc_file, kernels, what):
+    d = json.load(open(os.path.join(src, pmc_file)))
+    out = {}
+    for k in kernels:
+        e = d["kernels"].get(k)
+        if not e:
+            continue
+        r = e["derived"]
+        out[k] = {"hbm_bytes_per_unit": r.get("hbm_bytes_per_unit"), "valu_insts_per_unit": r.get("valu_insts_per_unit"),
+                  "salu_insts_per_unit": r.get("salu_insts_per_unit"), "lane_utilisation": r.get("lane_utilisation"),
+                  "lds_bank_conflict_per_lds_active": r.get("lds_bank_conflict_per_lds_active"),
+                  "units_profiled": r.get("units"), "dispatches_profiled": r.get("dispatches"),
+                  "source": f"profiles/{rnd}_{pmc_file}: scripts/pmc_all.sh, separate rocprofv3 --pmc passes of `{what}` (one render, no warm-up), counters "
+                            "summed over all dispatches of the kernel / the units the render states for it; HBM bytes = FETCH_SIZE x 2 (gfx950 "
+                            "wide-read correction, MI355X_MICROARCH.md HBM) + WRITE_SIZE, KiB -> B"}
+    return out
+
+
+traffic = {}
+if os.path.exists(os.path.join(src, "pmc_headline.json")):
+    traffic["headline"] = entries("pmc_headline.json", ["k_path"], "scripts/bench_scene.py 0 1920 1080 256 50")
+if os.path.exists(os.path.join(src, "pmc_scene1.json")):
+    traffic["c3"] = entries("pmc_scene1.json", ["k_first", "k_trace", "k_shade", "k_bounce"], "scripts/bench_scene.py 1 1920 1080 256 50")
+if os.path.exists(os.path.join(src, "pmc_scene3.json")):
+    traffic["c4"] = entries("pmc_scene3.json", ["k_path"], "scripts/bench_scene.py 3 1920 1080 256 50")
 json.dump(traffic, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 json.dump(traffic, open(os.path.join(dst, f"{rnd}_pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(traffic["k_path"], indent=1))
+for cfg, ks in traffic.items():
+    for k, v in ks.items():
+        print(cfg, k, {a: (round(b, 3) if isinstance(b, float) else b) for a, b in v.items() if a != "source"})
