@@ -120,6 +120,8 @@ struct PathConsts {
     // what the end of a sample block needs (k_path: a branch that one or two lanes of a wave take in two iterations out of three):
     // read from here, these launch constants do not sit in SGPRs - which the loop has none to spare of - between those visits
     uint32_t npix, width, row0, row_stride, divs_m, divs_s1, divs_s2, spp, bs_lo, bs_hi, unit_shift, pad3;
+    // what handing out units needs (the refill at the top of the loop: every few iterations of a wave)
+    uint32_t n_jobs, n_ranges, units_per_job, unit_blocks, n_blocks_pass, block0, divw_m, divw_s1, divw_s2, q_lo, q_hi, pad4;
 };
 
 // probes = the scene lists lights: only then can a vertex queue a shadow probe (shade_a), so plane p2 - the probe's
@@ -1413,6 +1415,9 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
         s_pc.divs_m = A.divs_m; s_pc.divs_s1 = A.divs_s1; s_pc.divs_s2 = A.divs_s2; s_pc.spp = A.spp;
         s_pc.bs_lo = (uint32_t)(uint64_t)A.blocksum; s_pc.bs_hi = (uint32_t)((uint64_t)A.blocksum >> 32);
         s_pc.unit_shift = A.unit_sums ? 3u : 0u; s_pc.pad3 = 0u;
+        s_pc.n_jobs = A.n_jobs; s_pc.n_ranges = A.n_ranges; s_pc.units_per_job = A.units_per_job; s_pc.unit_blocks = A.unit_blocks;
+        s_pc.n_blocks_pass = A.n_blocks_pass; s_pc.block0 = A.block0; s_pc.divw_m = A.divw_m; s_pc.divw_s1 = A.divw_s1; s_pc.divw_s2 = A.divw_s2;
+        s_pc.q_lo = (uint32_t)(uint64_t)A.queue; s_pc.q_hi = (uint32_t)((uint64_t)A.queue >> 32); s_pc.pad4 = 0u;
     }
     // the LDS camera serves the perspective camera without a lens (the reference's only camera); other kinds read the arguments
     // (the host sends other camera kinds and thin lenses through the cold instantiation, which reads the arguments)
@@ -1444,30 +1449,33 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) 
         RTW_MARK("refill");
         unsigned long long need_mask = __ballot(need);
         while (need_mask != 0ull && !exhausted) {
+            const PathConsts* kc = &s_pc;  // (launch constants from the LDS page: see PathConsts)
             if (u_next >= u_end) {
                 uint32_t q = 0;
-                if (lane == 0) q = atomicAdd(A.queue, 1u);
+                if (lane == 0) q = atomicAdd((uint32_t*)(((uint64_t)kc->q_hi << 32) | kc->q_lo), 1u);
                 q = __builtin_amdgcn_readfirstlane(q);
-                if (q >= A.n_jobs) { exhausted = true; break; }
-                const uint32_t gi = q / A.n_ranges;
+                if (q >= (uint32_t)__builtin_amdgcn_readfirstlane((int)kc->n_jobs)) { exhausted = true; break; }
+                const uint32_t n_ranges = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc->n_ranges), upj = (uint32_t)__builtin_amdgcn_readfirstlane((int)kc->units_per_job);
+                const uint32_t gi = q / n_ranges;
                 job_g = order_lookup(A, gi);
-                job_b = (q - gi * A.n_ranges) * A.units_per_job;
-                u_next = 0; u_end = 64u * A.units_per_job;
+                job_b = (q - gi * n_ranges) * upj;
+                u_next = 0; u_end = 64u * upj;
                 continue;
             }
             const uint32_t avail = u_end - u_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(need_mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)need_mask, 0u));
             if (need && rank < avail) {
+                const uint32_t ub = kc->unit_blocks, nbp = kc->n_blocks_pass;
                 const uint32_t u = u_next + rank;
-                const uint32_t b = (job_b + (u >> 6)) * A.unit_blocks;  // first block of the unit (blocks of this pass)
+                const uint32_t b = (job_b + (u >> 6)) * ub;  // first block of the unit (blocks of this pass)
                 const uint32_t p_local = job_g * 64u + (u & 63u);
-                if (p_local < A.npix && b < A.n_blocks_pass) {
+                if (p_local < kc->npix && b < nbp) {
                     need = false;
                     blk = b;
-                    blk_end = min(b + A.unit_blocks, A.n_blocks_pass);
-                    const uint32_t yl = fastdiv(p_local, A.divw_m, A.divw_s1, A.divw_s2);
-                    pxy = (p_local - yl * A.width) | ((A.row0 + yl * A.row_stride) << 16);
-                    s_cur = (A.block0 + b) * kSumBlock;
+                    blk_end = min(b + ub, nbp);
+                    const uint32_t yl = fastdiv(p_local, kc->divw_m, kc->divw_s1, kc->divw_s2);
+                    pxy = (p_local - yl * kc->width) | ((kc->row0 + yl * kc->row_stride) << 16);
+                    s_cur = (kc->block0 + b) * kSumBlock;
                     usum = V(0.f, 0.f, 0.f);
                     alive = false;
                 }
