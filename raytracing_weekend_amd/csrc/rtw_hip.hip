@@ -281,6 +281,7 @@ struct Tuning {
     size_t lds_kb = 16;
     int trace_block = 256;       // threads per workgroup of k_trace_bvh (256, 512, 1024)
     size_t trace_lds_kb = 16;    // its LDS budget: stacks + tree nodes + leaf records
+    bool trace_auto = true;      // neither RTW_TRACE_BLOCK nor RTW_TRACE_LDS_KB given: the render picks the pair (see render_single)
     int trace_waves = 6;         // waves per SIMD it is launched for
     int stagger_pct = -1;  // -1 = automatic
     int tail_group = 2;
@@ -316,8 +317,8 @@ Tuning read_tuning() {
     if (geti("RTW_SPLIT_MEDIA", v)) t.split_media = v != 0;
     if (geti("RTW_BRUTE_MAX", v)) t.brute_max = (int)v;
     if (geti("RTW_LDS_KB", v)) t.lds_kb = (size_t)std::max<long long>(0, v);
-    if (geti("RTW_TRACE_BLOCK", v) && (v == 256 || v == 512 || v == 1024)) t.trace_block = (int)v;
-    if (geti("RTW_TRACE_LDS_KB", v)) t.trace_lds_kb = (size_t)std::max<long long>(0, std::min<long long>(150, v));
+    if (geti("RTW_TRACE_BLOCK", v) && (v == 256 || v == 512 || v == 1024)) { t.trace_block = (int)v; t.trace_auto = false; }
+    if (geti("RTW_TRACE_LDS_KB", v)) { t.trace_lds_kb = (size_t)std::max<long long>(0, std::min<long long>(150, v)); t.trace_auto = false; }
     if (geti("RTW_TRACE_WAVES", v)) t.trace_waves = (int)std::max<long long>(1, std::min<long long>(8, v));
     if (geti("RTW_TAIL_GROUP", v)) t.tail_group = (int)std::max<long long>(1, std::min<long long>(64, v));
     if (geti("RTW_FIRST_GROUP_LOG2", v)) t.first_group_log2 = (int)std::max<long long>(0, std::min<long long>(8, v));
@@ -1118,15 +1119,41 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
     const bool paired = false;  // (measured 12 % slower: -DRTW_EXPERIMENTS builds only)
 #endif
     // k_trace_bvh: large workgroups share one LDS copy of the tree (nodes, then leaf records) between more waves
-    const int trace_block = tune.trace_block;
+    int trace_block = tune.trace_block;
+    size_t trace_budget = tune.trace_lds_kb * 1024;
+    // LDS the trace launch may plan with per CU: all 160 KB when the knobs say so; 142 KB when the render chooses - the other
+    // lane's kernels (k_shade: 9 KB per workgroup) must find room beside a resident k_trace_bvh, or the two lanes take turns
+    size_t trace_cu_lds = (size_t)160 * 1024;
+    if (c->sc.use_bvh && tune.trace_auto) {
+        // Every node of the tree in the workgroup's LDS image takes the global loads - and the vmcnt waits behind them - out of the
+        // walk loop (k_trace_bvh mode 2), but only pays while the kernel keeps its waves AND leaves the other lane room: a 256-thread
+        // workgroup at 6 per CU has 14 KB for stacks + nodes (scene 1's stacks alone: 21 levels = 10.75 KB), a 512-thread workgroup
+        // shares one image between twice the waves. Measured (round 3, scene 1: 240 nodes = 15.4 KB; k_trace_bvh per 512-spp render):
+        // 256 threads / 16 KB (88 nodes in LDS, the old default) 0.152-0.155 s; 256 / 26 KB (all nodes, 4 waves per SIMD) 0.154;
+        // 512 / 37 KB (all nodes, 3 workgroups = 141 KB per CU) 0.144-0.147; 512 / 40.5 KB (152 KB per CU: no room left for the
+        // other lane's workgroups) 0.155; 512 / 43 KB (three planned, two fit) 0.166; 512 / 44 KB (two planned) 0.143-0.145.
+        // Scene 2: 0.163 -> 0.153. Scene 4 (1 419 nodes = 91 KB) stays at 256 / 16 KB.
+        const size_t cu_lds = (size_t)142 * 1024;
+        const size_t blocks[2] = {256, 512};
+        for (size_t blk : blocks) {
+            int32_t nn = 0, nl = 0;
+            const size_t want = std::max<size_t>(1, (size_t)(4 * tune.trace_waves) / (blk / 64));  // workgroups per CU at the wanted occupancy
+            const size_t fixed = (kMaxRegions + 1 + blk) * 4 + 64;                                // the work list's static LDS
+            // stacks + every node, no leaf records (a partial leaf image makes a wave run both of leaf_test's fetch paths)
+            const size_t need = tree_lds_layout(c->n_tree_nodes, 0, c->stack_depth, c->sc.stack_wide != 0, blk, (size_t)150 * 1024, nn, nl);
+            if ((size_t)nn != c->n_tree_nodes) continue;
+            const size_t fit = cu_lds / (need + fixed);
+            if (fit >= want || (blk == 512 && fit >= 2)) { trace_block = (int)blk; trace_budget = need; trace_cu_lds = cu_lds; break; }
+        }
+    }
     int32_t trace_nodes = 0, trace_leaves = 0;
     size_t trace_lds = 0;
     int trace_grid = 0;
     if (c->sc.use_bvh) {
-        trace_lds = tree_lds_layout(c->n_tree_nodes, c->n_tree_leaves, c->stack_depth, c->sc.stack_wide != 0, (size_t)trace_block, tune.trace_lds_kb * 1024,
+        trace_lds = tree_lds_layout(c->n_tree_nodes, c->n_tree_leaves, c->stack_depth, c->sc.stack_wide != 0, (size_t)trace_block, trace_budget,
                                     trace_nodes, trace_leaves);
         const size_t per_wg = trace_lds + (kMaxRegions + 1 + (size_t)trace_block) * 4 + 64;
-        const size_t by_lds = std::max<size_t>(1, (size_t)160 * 1024 / per_wg);
+        const size_t by_lds = std::max<size_t>(1, trace_cu_lds / per_wg);
         const size_t by_waves = std::max<size_t>(1, (size_t)(4 * (paired ? tune.paired_trace_waves : tune.trace_waves)) / ((size_t)trace_block / 64));
         trace_grid = (int)((size_t)c->n_cu * std::min(by_lds, by_waves));
         if (trace_lds > 48 * 1024) {  // beyond the default dynamic-LDS limit of a launch
@@ -1228,7 +1255,7 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
             a.cnt_out = L.cnt;
             a.depth = 0; a.n_iter = 1;
             launches++;
-            return timed_launch(L.st, LK_FIRST, a, (int)R.regions, lds);  // every compacting launch uses exactly this grid: workgroup b owns region b
+            return timed_launch(L.st, LK_FIRST, a, (int)R.regions, c->sc.use_bvh ? (size_t)(kBlock / 64) * (size_t)c->stack_depth * sizeof(uint32_t) : 0);  // every compacting launch uses exactly this grid: workgroup b owns region b
         };
         // step si of the schedule for a batch; a trace launch may wait for an event of the other lane and record one
         auto run_step = [&](BatchRun& R, size_t si, hipEvent_t wait_for, hipEvent_t record) -> hipError_t {

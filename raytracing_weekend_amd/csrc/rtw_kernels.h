@@ -66,7 +66,13 @@ RTW_DEV void rtw_sub_stamp(int id) {
 #define RTW_SUB(id)
 #endif
 constexpr int kBlock = 256;                       // 4 wave64 per workgroup
-constexpr uint32_t kMaxRegions = 2048;            // region counters scanned in LDS by every workgroup (>= the compacting grid)
+#ifndef RTW_MAX_REGIONS
+#define RTW_MAX_REGIONS 1024
+#endif
+// 1 024 regions = 4 compacting workgroups per CU (what two lanes use; a single lane used to take 8). Round 3 halved the table: it is
+// static LDS of every wavefront kernel (4 KB instead of 8), and LDS is what decides whether the other lane's workgroups find room
+// on a CU beside a resident k_trace_bvh (scene 4 +5 %, scene 1 +2 %).
+constexpr uint32_t kMaxRegions = RTW_MAX_REGIONS;            // region counters scanned in LDS by every workgroup (>= the compacting grid)
 constexpr uint32_t kZombie = 0x80000000u;
 constexpr uint32_t kNeePrev = 0x40000000u;       // gk bit 30 (corrected estimator): a light sample was taken at the previous vertex
 
@@ -774,7 +780,9 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_FIRST_WAVES)
     const uint32_t tid = threadIdx.x;
     cursor_init(s_cursor);
     const uint32_t* noise_lds = stage_noise<(TEX != 0)>(A.sc, s_noise);
-    const TravMem tm = trav_mem(A.sc, s_stack, kBlock, tid);
+    // (no per-lane stacks and no LDS image of the tree here: the camera rays of a wave walk the tree as one, with one stack per
+    // wave - stack_depth dwords of dynamic LDS each - and the node records as scalar operands; scenes without a tree walk the
+    // candidate lists. What this kernel does not take of a CU's LDS, the other lane's k_trace_bvh can.)
     uint32_t n_seg = 0, n_shadow = 0;
     const uint32_t total_chunks = (A.n_paths + kBlock - 1) / kBlock;
     for (uint32_t vc = blockIdx.x; vc < total_chunks; vc += gridDim.x) {
@@ -811,19 +819,16 @@ __global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_FIRST_WAVES)
             // and a wave-uniform test against the scene bounds spares them the walk over the candidate lists
             th = 1.e27f; prim = -1;
             if (__ballot(may_hit_scene(A.sc, p.o, p.d)) != 0ull) {
-#ifndef RTW_FIRST_LANE_WALK
                 if (A.sc.use_bvh) {
-                    // the camera rays of a wave walk the tree together (rtw_device.h traverse_wave); volumes first, per lane, as in
-                    // traverse<>. The wave's stack: one 32-bit entry per level in the rows of its per-lane stack columns
+                    // rtw_device.h traverse_wave; volumes first, per lane, as in traverse<>
                     bool vol = false;
                     if (TEX && A.sc.n_vol > 0) vol = volume_pass<Rng<KIND>, false>(A.sc, p.o, p.d, A.sc.ray_tmin, p.ray_time, gt, g, th, prim);
-                    const uint32_t wv = tid >> 6;
-                    uint32_t* wstack = tm.wide ? s_stack + 2u * kBlock + 64u * wv : s_stack + kBlock + 32u * wv;
-                    traverse_wave(A.sc, wstack, tm.wide ? (uint32_t)kBlock : (uint32_t)kBlock / 2u, true, p.o, p.d, A.sc.ray_tmin, p.ray_time, gt, th, prim, vol);
-                } else
-#endif
-                if (TEX && A.sc.n_vol > 0) traverse<Rng<KIND>, false, false>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, g, tm, th, prim);
-                else traverse<NoRng, false, true>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, ng, tm, th, prim);
+                    traverse_wave(A.sc, s_stack + (tid >> 6) * (uint32_t)A.sc.stack_depth, 1u, true, p.o, p.d, A.sc.ray_tmin, p.ray_time, gt, th, prim, vol);
+                } else if (TEX && A.sc.n_vol > 0) {
+                    traverse_brute<Rng<KIND>, false, false>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, g, th, prim);
+                } else {
+                    traverse_brute<NoRng, false, true>(A.sc, p.o, p.d, A.sc.ray_tmin, 1.e27f, p.ray_time, gt, ng, th, prim);
+                }
             }
             v3 so, sd, att, radiance;
             Nee nee;
