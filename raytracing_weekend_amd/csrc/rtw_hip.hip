@@ -243,7 +243,8 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 }
 
 // Tuning knobs, read from the environment once per call site (defaults are what profiles/ was measured with):
-//   RTW_POOL_PATHS  paths in flight over all lanes (default 2^28: 55 GiB of state, sized for 288 GB of HBM)
+//   RTW_POOL_PATHS  paths in flight over all lanes (default 2^29: up to 120 GiB of state for a full-HD frame at 512+ spp, sized for
+//                   288 GB of HBM; round 3: 2^28 -> 2^29 halves the batches of BASELINE config 3: +5 %)
 //   RTW_LANES       stream lanes that overlap consecutive batches (default 2; 1..4)
 //   RTW_GRID_MULT   persistent workgroups per CU (default 8 with one lane, 4 with two)
 //   RTW_TAIL_START  first bounce handled by the fused multi-bounce tail launches (default 6; 20 for tree scenes, 40 for tree scenes with media)
@@ -271,7 +272,7 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_BLOCKSUM_BYTES   cap of the k_path block-sum buffer (default 16 GiB); larger renders run in passes over the samples
 //   RTW_KERNEL_TIMING    0: no per-launch events even when the caller asks for rtw_stats (kernel_seconds stay 0)
 struct Tuning {
-    size_t pool_paths = (size_t)1 << 28;
+    size_t pool_paths = (size_t)1 << 29;
     int lanes = 2;
     int grid_mult = 0;   // 0 = automatic
     int tail_start = 0;  // 0 = automatic: 6 for the brute-list scenes, 20 for tree scenes (40 with media)
@@ -1095,6 +1096,16 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
                                        : std::max<size_t>(1, tune.pool_paths / (size_t)want_lanes / npix);
     S = std::min<size_t>(S, (size_t)P->spp);
     while (S > 1 && npix * S > 0xfffffff0ull) S--;
+    if (P->samples_per_pass <= 0 && want_lanes > 1 && (size_t)P->spp >= (size_t)want_lanes) {
+        // equal batches, as many as a multiple of the lanes: every lane gets the same number of batches of the same size (a
+        // render of 128 spp whose pool would take it in one batch would leave the second lane idle; 512 spp in batches of 129
+        // would end with a short fourth one). Sizes are kept multiples of 16 where that fits (k_first's sample grouping).
+        size_t nb = ((size_t)P->spp + S - 1) / S;
+        nb = (nb + (size_t)want_lanes - 1) / (size_t)want_lanes * (size_t)want_lanes;
+        size_t s_eq = ((size_t)P->spp + nb - 1) / nb;
+        if (((s_eq + 15) & ~(size_t)15) <= S) s_eq = (s_eq + 15) & ~(size_t)15;
+        S = std::max<size_t>(1, std::min(S, s_eq));
+    }
     const size_t paths_max = npix * S;
     // Persistent compacting grid: G workgroups (8 per CU when a lane has the GPU to itself, 4 when two lanes share it).
     // Output region b belongs to workgroup b, which is handed every G-th 256-path chunk of its input: at most
