@@ -19,6 +19,22 @@ trace() {  # <name> <bench args...>
   local name=$1; shift
   timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$name -- python3 bench.py --no-cpu-baseline "$@" > $OUT/bench_under_rocprof_$name.log 2>&1
   cp $OUT/trace_$name/*/*kernel_stats.csv $OUT/kernel_stats_$name.csv
+  # the per-dispatch rows of the dominant kernels (start, duration): a k_path render is TWO overlapping dispatches
+  python3 - $OUT/trace_$name $OUT/kernel_trace_$name.csv <<'PY'
+import csv, glob, sys
+rows = []
+for f in glob.glob(sys.argv[1] + "/*/*kernel_trace.csv"):
+    for r in csv.DictReader(open(f)):
+        if "k_path<" in r["Kernel_Name"]:
+            rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Grid_Size_X", ""), r.get("Queue_Id", "")))
+rows.sort()
+if rows:
+    t0 = rows[0][0]
+    with open(sys.argv[2], "w") as o:
+        o.write("kernel,grid_x,queue,start_ms,duration_ms\n")
+        for a, b, n, g, q in rows:
+            o.write('"%s",%s,%s,%.3f,%.3f\n' % (n, g, q, (a - t0) / 1e6, (b - a) / 1e6))
+PY
   grep '^{"metric"' $OUT/bench_under_rocprof_$name.log > $OUT/bench_under_rocprof_$name.json || true
   rm -rf $OUT/trace_$name
   echo "trace $name done"
