@@ -279,7 +279,8 @@ def main():
         if in_regs:
             roof["bound_frac"] = valu["frac"] if valu else None
             roof["note"] = ("k_path never writes path state: the 64 B the algorithmic figure counts stay in registers and only 16 B per pixel "
-                            "and 16-sample block reach HBM (traffic), so HBM is idle and the kernel is bound by VALU issue: bound_frac = "
+                            "and 128-sample summation unit (per 16-sample block in the end-game region and in short renders) reach HBM "
+                            "(traffic), so HBM is idle and the kernel is bound by VALU issue: bound_frac = "
                             "roofline.valu.frac is the physical fraction, frac the north star's HBM-equivalent figure of merit. The pass's two "
                             "overlapping k_path launches are timed as one, from before the first to after both")
         else:
