@@ -266,7 +266,8 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //                   kind of step; bit-identical, measured 25-45 % slower than the wavefront kernels on scenes 1, 2, 4); 0 (default): wavefront
 //   RTW_PATH_UNIT_BLOCKS 16-sample blocks a lane takes as one unit in the bulk launch (default: 8 = 128 samples when a lane has
 //                        600+ blocks to do, else 4)
-//   RTW_PATH_FINE_BLOCKS blocks at the end of a pass that a second, concurrent launch hands out one by one (default 8: 128 samples)
+//   RTW_PATH_FINE_BLOCKS blocks at the end of a pass that a second, concurrent launch hands out one by one (default: 8 behind 8-block
+//                        units, 16 behind shorter ones)
 //   RTW_PATH_JOB_BLOCKS  units per pixel in one k_path job (default 2: a job is 64 pixels x 2 units)
 //   RTW_PATH_GRID_MULT   k_path workgroups per CU (default: what the occupancy query admits)
 //   RTW_BLOCKSUM_BYTES   cap of the k_path block-sum buffer (default 16 GiB); larger renders run in passes over the samples
@@ -295,7 +296,7 @@ struct Tuning {
     int path_tree = 0;
     int path_job_blocks = 2;
     int path_unit_blocks = 0;    // 0 = automatic (8 for large renders, else 4)
-    int path_fine_blocks = 8;
+    int path_fine_blocks = -1;   // -1 = automatic (8 behind 8-block units, 16 behind shorter ones)
     int path_grid_mult = 0;
     size_t blocksum_bytes = (size_t)16 << 30;
     bool kernel_timing = true;
@@ -330,7 +331,7 @@ Tuning read_tuning() {
     if (geti("RTW_PATH_TREE", v)) t.path_tree = v != 0;
     if (geti("RTW_PATH_JOB_BLOCKS", v)) t.path_job_blocks = (int)std::max<long long>(1, std::min<long long>(1024, v));
     if (geti("RTW_PATH_UNIT_BLOCKS", v)) t.path_unit_blocks = (int)std::max<long long>(0, std::min<long long>(4096, v));
-    if (geti("RTW_PATH_FINE_BLOCKS", v)) t.path_fine_blocks = (int)std::max<long long>(0, std::min<long long>(4096, v));
+    if (geti("RTW_PATH_FINE_BLOCKS", v)) t.path_fine_blocks = (int)std::max<long long>(-1, std::min<long long>(4096, v));
     if (geti("RTW_PATH_GRID_MULT", v)) t.path_grid_mult = (int)std::max<long long>(1, std::min<long long>(16, v));
     if (geti("RTW_BLOCKSUM_BYTES", v) && v >= (1 << 16)) t.blocksum_bytes = (size_t)v;
     if (geti("RTW_KERNEL_TIMING", v)) t.kernel_timing = v != 0;
@@ -1008,7 +1009,11 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
         // blocks per lane): 0.0773, 0.0722, 0.0736 s; on the 1/2 shard 8 and 4 are level.
         const size_t blocks_per_lane = npix * n_blocks / ((size_t)c->n_cu * (size_t)wg_per_cu * kBlock);
         const size_t U = tune.path_unit_blocks > 0 ? (size_t)tune.path_unit_blocks : (blocks_per_lane >= 600 ? 8 : 4);
-        const size_t F = (size_t)tune.path_fine_blocks;
+        // the end-game region: the last 8 blocks of a pass behind 8-block units, the last 16 behind 4-block units (a shard-sized
+        // render: the bulk launch drains for a unit's length at its end, and the single-block work beside it must last that long;
+        // 1/8 shard of the metric frame, medians of 12 runs: F = 8 0.0739 s, 16 0.0725, 24 0.0728, 32 0.0727, 48 0.0729; the full
+        // frame does not care: 0.5597 against 0.5593)
+        const size_t F = tune.path_fine_blocks >= 0 ? (size_t)tune.path_fine_blocks : (U >= 8 ? 8 : 16);
         // Sums in memory (the arithmetic spec's three levels, rtw.h): a bulk launch whose lane units are whole summation units
         // (U a multiple of 8 blocks) stores ONE float4 per unit and pixel, everything else one per block; k_resolve_blocks adds
         // them up in the spec's order. A pass covers a multiple of 8 blocks, so no summation unit straddles two passes.
