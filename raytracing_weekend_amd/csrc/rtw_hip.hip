@@ -112,6 +112,7 @@ struct rtw_ctx {
     std::vector<rtw_ctx*> kids;
     float4* stage = nullptr;
     size_t stage_pix = 0;
+    size_t pool_cap = ~(size_t)0;  // paths in flight this device has room for (halved when a pool allocation fails: render_single)
     struct Worker* worker = nullptr;  // a kid's host thread: created with the group, lives until rtw_destroy
 };
 
@@ -1098,7 +1099,7 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
     // samples per pass: keep about pool_target paths in flight, split over the lanes
     const int want_lanes = tune.lanes;
     size_t S = P->samples_per_pass > 0 ? (size_t)P->samples_per_pass
-                                       : std::max<size_t>(1, tune.pool_paths / (size_t)want_lanes / npix);
+                                       : std::max<size_t>(1, std::min(tune.pool_paths, c->pool_cap) / (size_t)want_lanes / npix);
     S = std::min<size_t>(S, (size_t)P->spp);
     while (S > 1 && npix * S > 0xfffffff0ull) S--;
     if (P->samples_per_pass <= 0 && want_lanes > 1 && (size_t)P->spp >= (size_t)want_lanes) {
@@ -1216,6 +1217,15 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
     }
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
     int rc = ensure_pool(c, n_lanes, (size_t)regions_max * region_cap_max, npix, cnt_words);
+    if (rc == RTW_ERR_OOM && P->samples_per_pass <= 0 && S > 1) {
+        // The pool is sized for an MI355X to itself (2^29 paths: up to 120 GiB). A device with less to give - another process on
+        // it, a smaller part - gets half as many paths in flight, and half again, until the allocation fits: smaller batches,
+        // the same image (a path's draws and a pixel's summation order do not depend on the batch size).
+        free_pool(c);
+        (void)hipGetLastError();
+        c->pool_cap = std::max<size_t>((size_t)want_lanes * npix, npix * S * (size_t)want_lanes / 2);
+        return render_single(c, P, d_rgba, s, stats);
+    }
     if (rc) return rc;
 
     HIP_TRY_C(hipEventRecord(ev_begin, s));

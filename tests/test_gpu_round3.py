@@ -219,3 +219,27 @@ def test_experimental_kernels_stay_bit_exact(tmp_path):
     assert run({"RTW_HIP_LIB": lib}) == want
     assert run({"RTW_HIP_LIB": lib, "RTW_PATH_TREE": "1"}) == want
     assert run({"RTW_HIP_LIB": lib, "RTW_PAIRED": "1", "RTW_POOL_PATHS": "200000"}) == want
+
+
+def test_pool_that_does_not_fit_is_halved_not_refused(monkeypatch):
+    """The wavefront pipeline keeps up to 2^29 paths in flight (120 GiB of state on an MI355X it has to itself). When the
+    allocation fails - here: a pool of 2^33 paths asked for through the knob, 2 TB - the render halves the pool until it fits
+    instead of returning RTW_ERR_OOM, and the image is the one the default pool gives."""
+    W, H, spp = 1920, 1080, 1024
+    blob = abi.build_scene(1, W, H)
+    want = None
+    for pool in (None, str(1 << 33)):
+        if pool is None:
+            monkeypatch.delenv("RTW_POOL_PATHS", raising=False)
+        else:
+            monkeypatch.setenv("RTW_POOL_PATHS", pool)
+        r = abi.Renderer(0)
+        try:
+            r.upload_scene(blob)
+            img, st = r.render(abi.make_params(W, H, spp, 50))  # 2 lanes x 512 spp x 2 M pixels x 240 B = 509 GB asked for first
+        finally:
+            r.close()
+        if want is None:
+            want = (img, st.segments)
+        else:
+            assert np.array_equal(img, want[0]) and st.segments == want[1]
