@@ -257,7 +257,7 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_PAIRED=1    tree scenes, two lanes: batches run in pairs whose trace launches alternate, so that a k_trace_bvh always has the
 //                   other batch's k_shade beside it (measured 12 % slower than the free-running lanes: off; RTW_PAIRED_TRACE_WAVES
 //                   = waves per SIMD of the trace kernel in that mode, default 4)
-//   RTW_FIRST_GROUP_LOG2  k_first: 2^n neighbouring threads start samples of one pixel (default 4; 0 = one sample of 64 pixels per wave)
+//   RTW_FIRST_GROUP_LOG2  k_first: 2^n neighbouring threads start samples of one pixel (default 3; 0 = one sample of 64 pixels per wave)
 //   RTW_STAGGER     how far the second lane starts behind the first, in percent of a batch (its first batch is cut short by that
 //                   much; 0 = no offset). Default: 50 for the candidate-list scenes under RTW_PATH=0, 0 for tree scenes (there the
 //                   extra batch costs more than the offset gains: scenes 1, 2, 4 +1-4 % at 512+ spp, +6-13 % at 128-256 spp)
@@ -290,7 +290,9 @@ struct Tuning {
     int tail_group = 2;
     bool paired = false;         // RTW_PAIRED=1: tree scenes, two lanes: the batches of a pair alternate their trace launches
     int paired_trace_waves = 4;  // RTW_PAIRED_TRACE_WAVES: waves per SIMD of k_trace_bvh then (room for the other batch's k_shade)
-    int first_group_log2 = 4;    // k_first: up to 2^this neighbouring threads take samples of one pixel (RTW_FIRST_GROUP_LOG2; 16:
+    int first_group_log2 = 3;    // k_first: up to 2^this neighbouring threads take samples of one pixel (RTW_FIRST_GROUP_LOG2; round 2: 16;
+                                 // round 3, with the wave-coherent walk: 8 (scene 1 medians of 5: 7 085 against 6 948-6 998 Msamples/s; 4: 7 091;
+                                 // 2: 7 066; 1: 7 011; scenes 2 and 4 do not care). Round 2's note on 16:
                                  // k_first -6 ... -14 %; at 64 the later launches lose more - their finished paths then write
                                  // 16-byte results npix apart - than k_first gains)
     int path = 1;
