@@ -91,6 +91,7 @@ struct rtw_ctx {
         uint32_t* cnt = nullptr;
         size_t cnt_words = 0;
         size_t paths = 0;
+        bool probes = false;   // the slabs hold the planes of scenes with listed lights (p2, a full p5) as well
     } lane[4];
     float4* accum = nullptr;   // per pixel: sum of the finished sample blocks
     float4* part = nullptr;    // per pixel: running sum of the current block (wavefront pipeline)
@@ -158,6 +159,7 @@ void free_lane(rtw_ctx::Lane& L) {
     if (L.lbuf) (void)hipFree(L.lbuf);
     L.lbuf = nullptr;
     L.paths = 0;
+    L.probes = false;
 }
 void free_pool(rtw_ctx* c) {
     for (auto& L : c->lane) {
@@ -180,28 +182,34 @@ hipError_t create_stream(hipStream_t* st, int cls /* 0 normal, 1 high, 2 low */)
     return hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio);
 }
 
-int ensure_lane(rtw_ctx* c, rtw_ctx::Lane& L, size_t paths, size_t cnt_words) {
+int ensure_lane(rtw_ctx* c, rtw_ctx::Lane& L, size_t paths, size_t cnt_words, bool probes) {
     if (!L.st) {
         const int idx = (int)(&L - c->lane);
         HIP_TRY(c, create_stream(&L.st, idx & 1));
         HIP_TRY(c, hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
         HIP_TRY(c, hipEventCreateWithFlags(&L.ev_free, hipEventDisableTiming));
     }
-    if (paths > L.paths) {
+    if (paths > L.paths || (probes && !L.probes)) {
+        paths = std::max(paths, L.paths);
         free_lane(L);
-        // the six state planes and the hit records of one ping-pong set live in one slab, page-aligned
-        const size_t plane = (paths * sizeof(float4) + 4095) & ~(size_t)4095;
+        // the state planes and the hit records of one ping-pong set live in one slab, page-aligned: with listed lights six
+        // 16-byte planes + the 8-byte hit records (104 B per path); without (no probe is ever queued: rtw_kernels.h store_path)
+        // p2 is not there and p5 is a plane of dwords: 76 B per path - a third less of what decides how large a batch can be
+        auto al = [](size_t v) { return (v + 4095) & ~(size_t)4095; };
+        const size_t full = al(paths * sizeof(float4));
+        const size_t sz[7] = {full, full, probes ? full : 0, full, full, probes ? full : al(paths * sizeof(uint32_t)), al(paths * sizeof(uint2))};
+        size_t off[8] = {0};
+        for (int k = 0; k < 7; k++) off[k + 1] = off[k] + sz[k];
         for (int b = 0; b < 2; b++) {
-            const size_t total = 7 * plane + 4096;
-            HIP_TRY(c, hipMalloc(&L.slab[b], total));
+            HIP_TRY(c, hipMalloc(&L.slab[b], off[7] + 4096));
             char* base = (char*)L.slab[b];
-            auto at = [&](int k) { return base + (size_t)k * plane; };
-            L.buf[b].p0 = (float4*)at(0); L.buf[b].p1 = (float4*)at(1); L.buf[b].p2 = (float4*)at(2);
-            L.buf[b].p3 = (float4*)at(3); L.buf[b].p4 = (float4*)at(4); L.buf[b].p5 = (uint4*)at(5);
-            L.hit[b] = (uint2*)at(6);
+            L.buf[b].p0 = (float4*)(base + off[0]); L.buf[b].p1 = (float4*)(base + off[1]); L.buf[b].p2 = (float4*)(base + off[2]);
+            L.buf[b].p3 = (float4*)(base + off[3]); L.buf[b].p4 = (float4*)(base + off[4]); L.buf[b].p5 = (uint4*)(base + off[5]);
+            L.hit[b] = (uint2*)(base + off[6]);
         }
         HIP_TRY(c, hipMalloc(&L.lbuf, paths * sizeof(float4)));
         L.paths = paths;
+        L.probes = probes;
     }
     if (cnt_words > L.cnt_words) {
         if (L.cnt) (void)hipFree(L.cnt);
@@ -212,9 +220,9 @@ int ensure_lane(rtw_ctx* c, rtw_ctx::Lane& L, size_t paths, size_t cnt_words) {
     return RTW_OK;
 }
 
-int ensure_pool(rtw_ctx* c, int n_lanes, size_t paths, size_t npix, size_t cnt_words) {
+int ensure_pool(rtw_ctx* c, int n_lanes, size_t paths, size_t npix, size_t cnt_words, bool probes = true) {
     for (int l = 0; l < n_lanes; l++) {
-        int rc = ensure_lane(c, c->lane[l], paths, cnt_words);
+        int rc = ensure_lane(c, c->lane[l], paths, cnt_words, probes);
         if (rc) return rc;
     }
     if (n_lanes == 0 && !c->d_queue) HIP_TRY(c, hipMalloc(&c->d_queue, 64));
@@ -244,8 +252,9 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 }
 
 // Tuning knobs, read from the environment once per call site (defaults are what profiles/ was measured with):
-//   RTW_POOL_PATHS  paths in flight over all lanes (default 2^29: up to 120 GiB of state for a full-HD frame at 512+ spp, sized for
-//                   288 GB of HBM; round 3: 2^28 -> 2^29 halves the batches of BASELINE config 3: +5 %)
+//   RTW_POOL_PATHS  paths in flight over all lanes (default 2^30: sized for 288 GB of HBM - a full-HD frame at 512+ spp takes 178 GB of
+//                   state without listed lights, 238 GB with; an allocation that fails is halved, see render_single. Round 3, BASELINE
+//                   config 3: 2^28 (8 batches of 64 spp) 6.7, 2^29 (4 x 128) 7.0, 2^30 (2 x 256) 7.3 Gsamples/s)
 //   RTW_LANES       stream lanes that overlap consecutive batches (default 2; 1..4)
 //   RTW_GRID_MULT   persistent workgroups per CU (default 8 with one lane, 4 with two)
 //   RTW_TAIL_START  first bounce handled by the fused multi-bounce tail launches (default 6; 20 for tree scenes, 40 for tree scenes with media)
@@ -274,7 +283,7 @@ void magic_div(uint32_t d, uint32_t& m, uint32_t& s1, uint32_t& s2) {
 //   RTW_BLOCKSUM_BYTES   cap of the k_path block-sum buffer (default 16 GiB); larger renders run in passes over the samples
 //   RTW_KERNEL_TIMING    0: no per-launch events even when the caller asks for rtw_stats (kernel_seconds stay 0)
 struct Tuning {
-    size_t pool_paths = (size_t)1 << 29;
+    size_t pool_paths = (size_t)1 << 30;
     int lanes = 2;
     int grid_mult = 0;   // 0 = automatic
     int tail_start = 0;  // 0 = automatic: 6 for the brute-list scenes, 20 for tree scenes (40 with media)
@@ -1218,7 +1227,7 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
         split_first = split;
     }
     const size_t cnt_words = (size_t)regions_max * (sched.size() + 2);
-    int rc = ensure_pool(c, n_lanes, (size_t)regions_max * region_cap_max, npix, cnt_words);
+    int rc = ensure_pool(c, n_lanes, (size_t)regions_max * region_cap_max, npix, cnt_words, c->sc.n_lights > 0);
     if (rc == RTW_ERR_OOM && P->samples_per_pass <= 0 && S > 1) {
         // The pool is sized for an MI355X to itself (2^29 paths: up to 120 GiB). A device with less to give - another process on
         // it, a smaller part - gets half as many paths in flight, and half again, until the allocation fits: smaller batches,
