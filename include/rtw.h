@@ -265,9 +265,11 @@ int rtw_abi_version(void);
  * n_devices == 1: one context on device_ids[0] (NULL: device 0).
  * n_devices  > 1: a group. rtw_upload_scene copies the scene to every device; rtw_render / rtw_render_device split the
  * rows of the call into n_devices interleaved shards (shard g: every n_devices-th row of the call's rows, starting at its
- * g-th), render shard g on device_ids[g] from its own host thread, gather the float4 shards on device_ids[0] with one
- * hipMemcpyPeerAsync each (xGMI) and interleave them there: the caller sees one frame, bit-identical to the
- * single-device render. Entries of device_ids may repeat (two shards on one GPU). The caller stays single-threaded. */
+ * g-th), render shard g on device_ids[g] from that device's own host thread (created here, alive until rtw_destroy: no
+ * thread is created per call), every device pushes its float4 shard to device_ids[0] with one hipMemcpyPeerAsync on its
+ * own stream as soon as it is done (n concurrent xGMI transfers) and the rows are interleaved there: the caller sees one
+ * frame, bit-identical to the single-device render. Entries of device_ids may repeat (two shards on one GPU). The caller
+ * stays single-threaded; a worker that fails or throws reports through the call's return code. */
 int rtw_create(rtw_ctx** out, int n_devices, const int* device_ids);
 
 /* Replaces createSBT + initLaunchParams + the per-primitive optixAccelBuild calls
