@@ -1384,13 +1384,20 @@ RTW_DEV constexpr int rtw_phase_id(const char* n) { return n[0] == 'r' && n[2] =
 #else
 #define RTW_MARK(name) asm volatile("; MARK " name)
 #endif
-// waves per SIMD the register allocation aims at: 5 (<= 96 VGPRs) for the instantiation without the cold features - measured
-// +9 % over 4 on the metric workload, 6 adds nothing; the cold instantiation needs the registers more than the occupancy
+// waves per SIMD the register allocation aims at, for the instantiation without the cold features. Under the default scheduler: 5
+// (<= 96 VGPRs; +9 % over 4 on the metric workload, 6 added nothing). Round 3: the product build compiles this kernel's translation
+// unit with LLVM's register-pressure-first scheduler (-mllvm -amdgpu-sched-strategy=iterative-minreg, __graft_entry__.py UNIT_FLAGS)
+// and -DRTW_PATH_WAVES=6: 80 VGPRs + 48 B of scratch, 0.5292 s per render of the metric frame against 0.5565 (the phase fences
+// still pay under it: without them 0.549 at 5 waves). The cold instantiation needs the registers more than the occupancy
+// (BASELINE config 4 gains 4.5 % at 5 waves, the environment-camera scenes lose 27 %: left at RTW_MIN_WAVES)
 #ifndef RTW_PATH_WAVES
 #define RTW_PATH_WAVES 5
 #endif
+#ifndef RTW_PATH_COLD_WAVES
+#define RTW_PATH_COLD_WAVES RTW_MIN_WAVES
+#endif
 template <int KIND, int TEX>
-__global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_PATH_WAVES) k_path(const KArgs A) {
+__global__ void __launch_bounds__(kBlock, TEX ? RTW_PATH_COLD_WAVES : RTW_PATH_WAVES) k_path(const KArgs A) {
     RTW_NOISE_SHARED
     __shared__ u32x4 s_hitrec[kPathMaxPrims * 6];
     const uint32_t tid = threadIdx.x;
