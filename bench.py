@@ -75,9 +75,10 @@ def spawn_ranks(args):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, cwd=ROOT)
-    for line in proc.stdout:
-        sys.stdout.write(line)
-        sys.stdout.flush()
+    for line in proc.stdout:  # the JSON line goes to stdout, whatever else the ranks' libraries print there (gloo does) to stderr
+        out = sys.stdout if line.startswith('{"metric"') else sys.stderr
+        out.write(line)
+        out.flush()
     return proc.wait()
 
 
