@@ -54,6 +54,8 @@ namespace rtwk {
     extern template __global__ void K_<RTW_RNG_PHILOX, 0>(const KArgs); extern template __global__ void K_<RTW_RNG_PHILOX, 1>(const KArgs); extern template __global__ void K_<RTW_RNG_PHILOX, 2>(const KArgs); \
     extern template __global__ void K_<RTW_RNG_TEA_LCG, 0>(const KArgs); extern template __global__ void K_<RTW_RNG_TEA_LCG, 1>(const KArgs); extern template __global__ void K_<RTW_RNG_TEA_LCG, 2>(const KArgs);
 RTW_EXT(k_path)
+extern template __global__ void k_path<RTW_RNG_PHILOX, 1, 1>(const KArgs);
+extern template __global__ void k_path<RTW_RNG_TEA_LCG, 1, 1>(const KArgs);
 RTW_EXT(k_first)
 RTW_EXT(k_shade)
 RTW_EXT(k_bounce)
@@ -395,7 +397,14 @@ void launch(int which, int rng_kind, const KArgs& a, int grid, size_t lds, hipSt
         else if (a.sc.n_generic == 0) hipLaunchKernelGGL((k_trace<true>), dim3(grid), dim3(kBlock), lds, s, a);
         else hipLaunchKernelGGL((k_trace<false>), dim3(grid), dim3(kBlock), lds, s, a);
         break;
-    case LK_PATH: RTW_LAUNCH_SHADING(k_path, lds); break;
+    case LK_PATH:
+        if (feat == 1 && a.sc.n_vol > 0) {  // media scenes: the cold instantiation allocated for 5 waves (rtw_kernels.h k_path MEDIA5)
+            if (lcg) hipLaunchKernelGGL((k_path<RTW_RNG_TEA_LCG, 1, 1>), dim3(grid), dim3(kBlock), lds, s, a);
+            else hipLaunchKernelGGL((k_path<RTW_RNG_PHILOX, 1, 1>), dim3(grid), dim3(kBlock), lds, s, a);
+        } else {
+            RTW_LAUNCH_SHADING(k_path, lds);
+        }
+        break;
 #ifdef RTW_EXPERIMENTS
     case LK_PATH_TREE: RTW_LAUNCH_SHADING(k_path_tree, lds); break;
 #endif
@@ -987,7 +996,11 @@ int render_single(rtw_ctx* c, const rtw_params* P, void* d_rgba, hipStream_t s, 
 #ifdef RTW_EXPERIMENTS
             if (path_tree) qe = RTW_OCC(k_path_tree); else
 #endif
-            qe = RTW_OCC(k_path);
+            if (feat == 1 && base.sc.n_vol > 0)
+                qe = lcg ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_TEA_LCG, 1, 1>, kBlock, path_lds)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_path<RTW_RNG_PHILOX, 1, 1>, kBlock, path_lds);
+            else
+                qe = RTW_OCC(k_path);
 #undef RTW_OCC
 #undef RTW_OCC_R
             wg_per_cu = (qe == hipSuccess && nb > 0) ? std::min(nb, 8) : 4;

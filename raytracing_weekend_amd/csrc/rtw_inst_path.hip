@@ -14,6 +14,8 @@ namespace rtwk {
     template __global__ void K_<RTW_RNG_TEA_LCG, 0>(const KArgs); template __global__ void K_<RTW_RNG_TEA_LCG, 1>(const KArgs); template __global__ void K_<RTW_RNG_TEA_LCG, 2>(const KArgs);
 RTW_INST(k_path)
 #undef RTW_INST
+template __global__ void k_path<RTW_RNG_PHILOX, 1, 1>(const KArgs);
+template __global__ void k_path<RTW_RNG_TEA_LCG, 1, 1>(const KArgs);
 template __global__ void k_classify<true>(const KArgs, uint32_t*, uint32_t*, uint32_t);
 template __global__ void k_classify<false>(const KArgs, uint32_t*, uint32_t*, uint32_t);
 }  // namespace rtwk

@@ -1396,8 +1396,11 @@ RTW_DEV constexpr int rtw_phase_id(const char* n) { return n[0] == 'r' && n[2] =
 #ifndef RTW_PATH_COLD_WAVES
 #define RTW_PATH_COLD_WAVES RTW_MIN_WAVES
 #endif
-template <int KIND, int TEX>
-__global__ void __launch_bounds__(kBlock, TEX ? RTW_PATH_COLD_WAVES : RTW_PATH_WAVES) k_path(const KArgs A) {
+// MEDIA5: the cold instantiation once more, allocated for 5 waves per SIMD: scenes with media wait on the volume records' loads and
+// gain from the occupancy (BASELINE config 4: +4.5 %), the other users of the cold features (other cameras, corrected
+// estimators, thin lenses) are VALU-bound like the hot instantiation and lose up to 27 % to the spills
+template <int KIND, int TEX, int MEDIA5 = 0>
+__global__ void __launch_bounds__(kBlock, TEX ? (MEDIA5 ? 5 : RTW_PATH_COLD_WAVES) : RTW_PATH_WAVES) k_path(const KArgs A) {
     RTW_NOISE_SHARED
     __shared__ u32x4 s_hitrec[kPathMaxPrims * 6];
     const uint32_t tid = threadIdx.x;
