@@ -1389,7 +1389,7 @@ RTW_DEV constexpr int rtw_phase_id(const char* n) { return n[0] == 'r' && n[2] =
 // unit with LLVM's register-pressure-first scheduler (-mllvm -amdgpu-sched-strategy=iterative-minreg, __graft_entry__.py UNIT_FLAGS)
 // and -DRTW_PATH_WAVES=6: 80 VGPRs + 48 B of scratch, 0.5292 s per render of the metric frame against 0.5565 (the phase fences
 // still pay under it: without them 0.549 at 5 waves). The cold instantiation needs the registers more than the occupancy
-// (BASELINE config 4 gains 4.5 % at 5 waves, the environment-camera scenes lose 27 %: left at RTW_MIN_WAVES)
+// (the environment-camera scenes lose 27 % at 5 waves: left at RTW_MIN_WAVES; scenes with media take MEDIA5 below)
 #ifndef RTW_PATH_WAVES
 #define RTW_PATH_WAVES 5
 #endif
