@@ -772,8 +772,11 @@ RTW_DEV void raygen(const KArgs& A, const uint32_t x, const uint32_t y, const ui
 #ifndef RTW_FIRST_WAVES
 #define RTW_FIRST_WAVES RTW_MIN_WAVES
 #endif
+#ifndef RTW_FIRST_COLD_WAVES
+#define RTW_FIRST_COLD_WAVES RTW_MIN_WAVES
+#endif
 template <int KIND, int TEX>
-__global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_FIRST_WAVES) k_first(const KArgs A) {
+__global__ void __launch_bounds__(kBlock, TEX ? RTW_FIRST_COLD_WAVES : RTW_FIRST_WAVES) k_first(const KArgs A) {
     extern __shared__ uint32_t s_stack[];
     RTW_CURSOR_SHARED
     RTW_NOISE_SHARED
@@ -1099,6 +1102,13 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
 #ifndef RTW_SHADE_WAVES
 #define RTW_SHADE_WAVES RTW_MIN_WAVES
 #endif
+// the instantiations with the cold features (textures, media, the corrected estimators) are allocated for 5 waves per SIMD (96 VGPRs
+// instead of 111): k_shade waits on its loads, and the smaller allocation fits beside more of the other lane's k_trace_bvh waves.
+// Round 3, same box, bit-exact: scene 4 2 072 -> 2 127 Msamples/s (k_shade 0.094 -> 0.085 s), scene 2 3 554 -> 3 629; at 6 waves
+// the spills cost 11-15 %. k_first's cold instantiations stay at 4: at 5 scene 2 gains another 2.5 %, scene 4 loses 2 %.
+#ifndef RTW_SHADE_COLD_WAVES
+#define RTW_SHADE_COLD_WAVES 5
+#endif
 // RTW_SHADE_SORT=1 (experiment, off): deal a chunk's paths to the threads by hit material. Measured: k_shade 4-7 % SLOWER on
 // scenes 1, 2, 4 with one lane or two. Round 3 repeated it with the material class carried in the hit record (no lookup at all) and
 // the next chunk's hit records fetched a chunk ahead: still 4 % slower on scene 1, 1-2 % on scenes 2 and 4 (bit-exact). The kernel
@@ -1109,7 +1119,7 @@ __global__ void __launch_bounds__(BLOCK, RTW_TRACE_BVH_WAVES) k_trace_bvh(const 
 #define RTW_SHADE_SORT 0
 #endif
 template <int KIND, int TEX>
-__global__ void __launch_bounds__(kBlock, TEX ? RTW_MIN_WAVES : RTW_SHADE_WAVES) k_shade(const KArgs A) {
+__global__ void __launch_bounds__(kBlock, TEX ? RTW_SHADE_COLD_WAVES : RTW_SHADE_WAVES) k_shade(const KArgs A) {
     RTW_WORKLIST_SHARED
     RTW_CURSOR_SHARED
     RTW_NOISE_SHARED
