@@ -296,7 +296,9 @@ struct Tuning {
     int trace_block = 256;       // threads per workgroup of k_trace_bvh (256, 512, 1024)
     size_t trace_lds_kb = 16;    // its LDS budget: stacks + tree nodes + leaf records
     bool trace_auto = true;      // neither RTW_TRACE_BLOCK nor RTW_TRACE_LDS_KB given: the render picks the pair (see render_single)
-    int trace_waves = 6;         // waves per SIMD it is launched for
+    int trace_waves = 5;         // waves per SIMD it is launched for (the kernel is compiled for 6: 78 VGPRs). 5 leaves a SIMD the 96 VGPRs of one
+                                 // wave of the other lane's k_shade; medians of 5 renders, 6 -> 5 -> 4: scene 1 7 242 / 7 285 / 7 072 Msamples/s,
+                                 // scene 2 3 593 / 3 664 / 3 646, scene 4 2 123 / 2 128 / 2 059 (profiles/r03_trace_waves_sweep.txt)
     int stagger_pct = -1;  // -1 = automatic
     int tail_group = 2;
     bool paired = false;         // RTW_PAIRED=1: tree scenes, two lanes: the batches of a pair alternate their trace launches
