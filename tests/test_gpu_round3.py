@@ -53,6 +53,40 @@ def test_baseline_configs_3_and_4_at_their_sample_counts(gpu, scene, spp, rows):
     check(band, ref, st_b, st_ref)
 
 
+@pytest.mark.parametrize("scene,spp", [(0, 64), (3, 32), (1, 2), (2, 1), (4, 1)])
+def test_whole_frames_at_metric_resolution(gpu, scene, spp):
+    """EVERY pixel of a 1920x1080 frame against the oracle, all five reference scenes (the bands of the other tests cover all
+    sample indices on a few rows; this covers all rows, columns, job orders and the frame's edges at a few samples): scene 0 at
+    64 spp (4 summation blocks through k_path's unit hand-out), scene 3 through the cold instantiation, the tree scenes through
+    the wavefront kernels with the sample count the oracle's single-threaded-per-row walk affords."""
+    W, H = 1920, 1080
+    blob = abi.build_scene(scene, W, H)
+    gpu.upload_scene(blob)
+    p = abi.make_params(W, H, spp, 50)
+    img, st = gpu.render(p)
+    ref, st_ref = oracle.render(blob, p, threads=64)
+    check(img, ref, st, st_ref)
+
+
+METRIC_FRAMES = os.path.join(ROOT, "tests", "golden", "metric_frames.json")
+
+
+@pytest.mark.parametrize("name", sorted(json.load(open(METRIC_FRAMES))) if os.path.exists(METRIC_FRAMES) else ["missing"])
+def test_whole_baseline_frames_match_the_oracle_hashes(gpu, name):
+    """The metric workload ITSELF - all 1920 x 1080 pixels at 4096 spp, 8.49 G samples - and BASELINE configs 1, 2 and 4 whole, at
+    their sample counts: SHA-256 of the image bytes and the sample / segment / probe counts against what the CPU oracle
+    produced for the same frame (tests/golden/metric_frames.json, written by tests/golden/make_metric_frame_hashes.py: ten
+    minutes of a 64-thread host, once; the bands were compared pixel by pixel with the GPU image when it was made). The tree
+    scenes' entries are whole frames at 64 / 32 / 16 spp (the oracle walks no tree)."""
+    import hashlib
+    g = json.load(open(METRIC_FRAMES))[name]
+    blob = abi.build_scene(g["scene"], g["width"], g["height"])
+    gpu.upload_scene(blob)
+    img, st = gpu.render(abi.make_params(g["width"], g["height"], g["spp"], g["max_depth"], seed=g["seed"]))
+    assert (st.samples, st.segments, st.shadow_rays) == (g["samples"], g["segments"], g["shadow_rays"])
+    assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == g["sha256"]
+
+
 @pytest.mark.parametrize("path", ["1", "0"])
 def test_headline_silhouette_rows_at_4096_spp(gpu, monkeypatch, path):
     """The metric workload at 4096 spp on the rows where whole waves skip the walk (may_hit_scene's wave vote, k_classify's

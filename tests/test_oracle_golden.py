@@ -30,6 +30,24 @@ def test_oracle_reproduces_golden_bit_for_bit(name):
     assert np.all(img[..., 3] == 1.0) and np.isfinite(img).all()
 
 
+def test_whole_frame_hashes_are_the_oracle_s():
+    """tests/golden/metric_frames.json (whole BASELINE frames at their sample counts, hashed: what the GPU suite compares its
+    renders with) was written by this oracle: its smallest entry, BASELINE config 1, is re-rendered here and hashed the same
+    way; the large ones take a 64-thread host minutes each (tests/golden/make_metric_frame_hashes.py)."""
+    import hashlib
+    import json
+    g = json.load(open(os.path.join(GOLD, "metric_frames.json")))
+    assert {"c1", "c2", "c4", "headline"} <= set(g)
+    for name, e in g.items():  # every entry was compared band by band with the GPU image when it was made
+        assert e["gpu_mismatching_pixels"] == 0 and e["gpu_counts_equal"] and e["gpu_sha256"] == e["sha256"], name
+        assert e["samples"] == e["width"] * e["height"] * e["spp"]
+    e = g["c1"]
+    img, st = oracle.render(abi.build_scene(e["scene"], e["width"], e["height"]),
+                            abi.make_params(e["width"], e["height"], e["spp"], e["max_depth"], seed=e["seed"]), threads=8)
+    assert hashlib.sha256(np.ascontiguousarray(img).tobytes()).hexdigest() == e["sha256"]
+    assert (st.samples, st.segments, st.shadow_rays) == (e["samples"], e["segments"], e["shadow_rays"])
+
+
 def test_thread_count_does_not_change_the_image():
     blob, p, rgb, _ = load_case("cornell_200x200_16spp_d4_philox")
     p.row0, p.row1 = 90, 110
