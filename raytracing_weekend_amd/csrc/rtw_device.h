@@ -450,7 +450,12 @@ RTW_DEV TravMem trav_mem(const DScene& sc, uint32_t* lds, uint32_t block, uint32
     tm.n_leaves = (uint32_t)sc.n_lds_leaves;
     if (tm.n_nodes) {
         const uint32_t nv = tm.n_nodes * 4u, nl = tm.n_leaves * 2u;
+#ifdef RTW_NODE_SWIZZLE
+        // quad k of node i sits at quad k ^ ((i >> 1) & 3) of the node's 64 bytes (see bvh_node_quads)
+        for (uint32_t i = tid; i < nv; i += block) cache[(i & ~3u) | ((i ^ (i >> 3)) & 3u)] = sc.nodes[i];
+#else
         for (uint32_t i = tid; i < nv; i += block) cache[i] = sc.nodes[i];
+#endif
         for (uint32_t i = tid; i < nl; i += block) cache[nv + i] = sc.leaves[i];
         __syncthreads();
     }
@@ -585,6 +590,21 @@ RTW_DEV bool prim_test(const rtw_prim& pr, v3 oo, v3 dd, v3 inv, float tmin, flo
 // sp is the byte offset of the top of this thread's stack column (0 = empty). A pop never branches: under the stack
 // lies a row that says "nothing left" (16-bit entries are sign-extended, so 0xffff reads as kBvhDone; references stay
 // below 0x8000 in that mode), and a walk that has popped it is over.
+// The four 16-byte quads of node i from the workgroup's LDS image. Lanes read quad k of DIFFERENT nodes in one ds_read_b128, and
+// nodes are 64 bytes apart: unswizzled, every lane's quad k lies in the same 4 of a 128-byte bank row's 8 quad positions (node
+// parity picks the half), so the instruction is served from 8 of the 32 banks. RTW_NODE_SWIZZLE stores quad k at position
+// k ^ ((i >> 1) & 3): one instruction's reads then spread over all positions. Measured (round 3, bit-exact, off by default): scene 1
+// 7 334 -> 7 207 Msamples/s, scene 2 3 693 -> 3 615 (medians of 3; k_trace_bvh +2.5 %): the six extra address instructions per
+// node cost more than the conflicts - same-node lanes near the root are broadcast reads either way.
+RTW_DEV void bvh_node_quads(const u32x4* nodes, uint32_t i, u32x4& q0, u32x4& q1, u32x4& q2, u32x4& q3) {
+    const u32x4* q = nodes + 4u * i;
+#ifdef RTW_NODE_SWIZZLE
+    const uint32_t f = (i >> 1) & 3u;
+    q0 = q[f]; q1 = q[f ^ 1u]; q2 = q[f ^ 2u]; q3 = q[f ^ 3u];
+#else
+    q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+#endif
+}
 RTW_DEV uint32_t bvh_top(const TravMem& tm, int sp) {
     if (tm.wide) return *(const uint32_t*)((const char*)tm.stack32 + (sp - (int)(tm.stride * 4u)));
     return (uint32_t)(int32_t)*(const int16_t*)((const char*)tm.stack16 + (sp - (int)(tm.stride * 2u)));
@@ -605,8 +625,7 @@ RTW_DEV uint32_t bvh_inner_step(const DScene& sc, const TravMem& tm, const v3 o,
     const uint32_t i = cur >> 2;
     u32x4 q0, q1, q2, q3;
     if (i < tm.n_nodes) {
-        const u32x4* q = tm.nodes + 4u * i;
-        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+        bvh_node_quads(tm.nodes, i, q0, q1, q2, q3);
     } else {
         const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + 4u * i);
         q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
@@ -671,8 +690,7 @@ RTW_DEV void bvh_step16(const DScene& sc, const TravMem& tm, const v3 o, const v
     const uint32_t i = cur >> 2;
     u32x4 q0, q1, q2, q3;
     if (ALL_LDS || i < tm.n_nodes) {
-        const u32x4* q = tm.nodes + 4u * i;
-        q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
+        bvh_node_quads(tm.nodes, i, q0, q1, q2, q3);
     } else {
         const RTW_CONST u32x4* q = (const RTW_CONST u32x4*)(uint64_t)(sc.nodes + 4u * i);
         q0 = q[0]; q1 = q[1]; q2 = q[2]; q3 = q[3];
