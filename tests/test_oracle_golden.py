@@ -41,6 +41,14 @@ def test_whole_frame_hashes_are_the_oracle_s():
     for name, e in g.items():  # every entry was compared band by band with the GPU image when it was made
         assert e["gpu_mismatching_pixels"] == 0 and e["gpu_counts_equal"] and e["gpu_sha256"] == e["sha256"], name
         assert e["samples"] == e["width"] * e["height"] * e["spp"]
+    # ... and the entries named after bench.py's configurations are those workloads (same scene, frame, samples, depth, seed)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("rtw_bench", os.path.join(abi.REPO_DIR, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for name in ("headline", "c2", "c4"):
+        c, e = bench.CONFIGS[name], g[name]
+        assert (c["scene"], c["w"], c["h"], c["spp"], bench.DEPTH, bench.SEED) == (e["scene"], e["width"], e["height"], e["spp"], e["max_depth"], e["seed"])
     e = g["c1"]
     img, st = oracle.render(abi.build_scene(e["scene"], e["width"], e["height"]),
                             abi.make_params(e["width"], e["height"], e["spp"], e["max_depth"], seed=e["seed"]), threads=8)
