@@ -1,7 +1,9 @@
-"""usage: fuzz_parity.py [n] [first_seed] [small] — GPU vs oracle on n synthetic scenes (tests/oracle.py random_scene) with random
+"""usage: fuzz_parity.py [n] [first_seed] [small|shards] — GPU vs oracle on n synthetic scenes (tests/oracle.py random_scene) with random
 image sizes, depths, sample counts, generators and estimators. `small`: only scenes that take k_path's instantiation without the
 cold features (<= 24 surfaces, no media, motion or textures, reference estimator: the LDS walk with its med3 / 64-bit-key tests),
-with sample counts that span several summation blocks. Prints every mismatch and a summary; exit code 1 on any."""
+with sample counts that span several summation blocks. `shards`: the general scenes rendered as what one rank of an N-GPU job or a
+progressive pass renders - a random row range, an interleaved row stride of 1..8, a random number of samples kept in flight per
+pass, larger sample counts. Prints every mismatch and a summary; exit code 1 on any."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -12,6 +14,7 @@ import oracle
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 small = len(sys.argv) > 3 and sys.argv[3] == "small"
+shards = len(sys.argv) > 3 and sys.argv[3] == "shards"
 r = abi.Renderer(0)
 bad = 0
 for seed in range(first, first + n):
@@ -27,6 +30,12 @@ for seed in range(first, first + n):
     if small:
         p.estimator = 0
         p.spp = int(rs.choice([1, 3, 63, 64, 65, 130, 200]))
+    if shards:
+        p.spp = int(rs.choice([1, 5, 17, 40, 70]))
+        p.row0 = int(rs.randint(0, h))
+        p.row1 = int(rs.randint(p.row0 + 1, h + 1))
+        p.row_stride = int(rs.randint(0, 9))
+        p.samples_per_pass = int(rs.choice([0, 0, 1, 3, 16, 33]))
     r.upload_scene(blob)
     img, st = r.render(p)
     ref, st_ref = oracle.render(blob, p, threads=16)
